@@ -1,0 +1,205 @@
+/*
+ * libpcc_hip.so — C-ABI of the MI355X-native encode/decode operators of the joint
+ * geometry+attribute point-cloud codec (ColorModel.compress / decompress / forward).
+ *
+ * The reference (/root/reference) has no FFI of its own: its operators are Python calls
+ * into MinkowskiEngine (model/model.py:3, model/transforms.py:3, model/blocks.py:3,
+ * model/entropy_models.py:5) and compressai (model/entropy_models.py:9-10).  Each entry
+ * point below names the reference call site(s) it replaces.  INTEGRATION.md shows the
+ * ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers unless marked "host".
+ *   - all buffers are caller-owned (torch tensors on the Python side); the library never
+ *     allocates device memory.  `stream` is a hipStream_t passed as void*.
+ *   - every function returns 0 on success or a negative PCC_ERR_* code; the message is
+ *     available from pcc_last_error() (thread-local).  No exceptions cross the ABI.
+ *   - coordinates: int32 [N,4] rows (batch, x, y, z), |x|,|y|,|z| < 32767, batch < 32767.
+ *   - features: fp32 row-major [N, C].  Neighbour tables: int32 [N_out, K], -1 = absent.
+ *   - hash table = (keys uint64[cap], vals int32[cap]), cap a power of two from
+ *     pcc_hash_capacity(); a table is immutable once built and may be read concurrently.
+ */
+#ifndef PCC_HIP_H
+#define PCC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCC_OK 0
+#define PCC_ERR_ARG (-1)
+#define PCC_ERR_HIP (-2)
+#define PCC_ERR_UNSUPPORTED (-3)
+#define PCC_ERR_DATA (-4)
+
+#define PCC_ACT_NONE 0
+#define PCC_ACT_RELU 1       /* ME.MinkowskiReLU */
+#define PCC_ACT_LEAKY_RELU 2 /* ME.MinkowskiLeakyReLU, slope 0.01 */
+
+int pcc_version(void);
+const char* pcc_last_error(void);
+/* Number of devices visible to the library and a short name of device `dev` (host). */
+int pcc_device_count(void);
+int pcc_device_name(int dev, char* out, int out_len);
+
+/* ---------------------------------------------------------------------------------------
+ * Coordinate manager (ME coordinate_map_*; every ME.SparseTensor(...) construction, e.g.
+ * model/model.py:59,64,122,188).
+ * ------------------------------------------------------------------------------------- */
+int64_t pcc_hash_capacity(int64_t n);
+
+/* Insert rows 0..n-1; table value = row index.  Duplicate coordinates keep the smallest
+ * row index and increment *dup_count (device int32, may be NULL). */
+int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
+                   int32_t* dup_count, void* stream);
+
+/* out_idx[i] = row of query i or -1.  (features_at_coordinates on on-grid integer queries:
+ * model/transforms.py:96,124,262; model/blocks.py:37,50; model/entropy_models.py:326,364,401;
+ * torch.isin of model/blocks.py:125.) */
+int pcc_hash_lookup(const uint64_t* keys, const int32_t* vals, int64_t cap, const int32_t* query,
+                    int64_t nq, int32_t* out_idx, void* stream);
+
+/* Scratch (int32 elements) needed by pcc_stride_map / pcc_children / pcc_compact_* for m candidates. */
+int64_t pcc_scan_scratch_elems(int64_t m);
+
+/* Output coordinate set of a stride-2 convolution on a tensor of stride `ts`
+ * (ME stride map; model/transforms.py:49-51, model/blocks.py:203,
+ * model/entropy_models.py:276,280, model/model.py:189-190):
+ * unique floor(c / 2ts) * 2ts, in order of first appearance.  out_coords has room for n
+ * rows; *out_count (device int64) receives the number of unique rows.  On return
+ * (keys, vals, cap) is the hash table of the OUTPUT set (cap >= pcc_hash_capacity(n)). */
+int pcc_stride_map(const int32_t* coords, int64_t n, int32_t ts, uint64_t* keys, int32_t* vals,
+                   int64_t cap, int32_t* scratch, int32_t* out_coords, int64_t* out_count,
+                   void* stream);
+
+/* Output coordinate set of a generative transposed convolution, kernel `ksize` (2 or 3),
+ * stride 2, on a tensor of stride `ts` (ME.MinkowskiGenerativeConvolutionTranspose:
+ * model/blocks.py:84, model/entropy_models.py:286,290; ConvolutionTranspose :298,302):
+ * unique c + off_k * ts/2.  Candidates are enumerated parent-major for ksize 3 and
+ * offset-major for ksize 2; the output keeps first appearances in that order.
+ * out_coords has room for n * ksize^3 rows; table as in pcc_stride_map
+ * (cap >= pcc_hash_capacity(n * ksize^3)). */
+int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, uint64_t* keys,
+                 int32_t* vals, int64_t cap, int32_t* scratch, int32_t* out_coords,
+                 int64_t* out_count, void* stream);
+
+/* Kernel map (ME kernel_map, cached per coordinate manager): for every output row j and
+ * kernel offset k, nbr[j*K + k] = input row at c_out + sign * off_k * step, or -1.
+ * sign = +1 for (strided) convolution with step = input tensor stride; sign = -1 for
+ * transposed / generative convolution with step = input stride / 2.
+ * group_mask[g] (uint32, one per 64 output rows) has bit k set iff some row of the
+ * group has a neighbour at offset k (used by pcc_conv_fwd to skip empty work). */
+int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys,
+                   const int32_t* in_vals, int64_t in_cap, int32_t ksize, int32_t step,
+                   int32_t sign, int32_t* nbr, uint32_t* group_mask, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Sparse convolution forward (ME.MinkowskiConvolution / *ConvolutionTranspose forward,
+ * 100+ instances: model/transforms.py:35-57,168-234; model/blocks.py:17-24,86-97,194-220;
+ * model/entropy_models.py:273-305) with the pointwise ops that follow it fused:
+ *   v = bias + sum_k in[nbr(j,k)] @ W[k]                 (k ascending, fixed order)
+ *   if film:     v = v * film[j, c] + film[j, cout + c]   (ScaledBlock, blocks.py:37-40)
+ *   v = act(v)                                            (MinkowskiReLU / LeakyReLU)
+ *   if residual: v += residual[j, c]                      (blocks.py:49-52)
+ * W is the ME kernel tensor [K, cin, cout] (fp32).  For cin % 32 == 0 the MFMA path is used
+ * and needs `w_packed` from pcc_conv_pack_weights; otherwise (cin in {1,2,4,8,16}) the
+ * thin path reads `w` directly.  nbr == NULL means kernel_size 1 (identity map, K = 1).
+ * ------------------------------------------------------------------------------------- */
+int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
+int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, float* w_packed,
+                          void* stream);
+int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed,
+                 const float* bias, const int32_t* nbr, const uint32_t* group_mask, int32_t K,
+                 float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film,
+                 const float* residual, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row movement: lookup-gather, pruning.
+ * ------------------------------------------------------------------------------------- */
+/* out[i,:] (+)= idx[i] >= 0 ? src[idx[i],:] : 0   (features_at_coordinates after
+ * pcc_hash_lookup; accumulate != 0 adds into out: model/transforms.py:96,262). */
+int pcc_gather_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out,
+                    int32_t accumulate, void* stream);
+
+/* out[idx[i],:] = src[i,:] for idx[i] >= 0 (re-indexing a tensor onto another map). */
+int pcc_scatter_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out,
+                     void* stream);
+
+/* ME.MinkowskiPruning (model/blocks.py:90,126): order-preserving compaction of the rows
+ * with mask != 0.  Either of feats/out_feats and coords/out_coords may be NULL.
+ * new_index[i] (optional) = output row of input row i or -1.  *out_count: device int64. */
+int pcc_compact_rows(const uint8_t* mask, int64_t n, const int32_t* coords, int32_t* out_coords,
+                     const float* feats, int32_t c, float* out_feats, int32_t* new_index,
+                     int32_t* scratch, int64_t* out_count, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Per-batch top-k on one logit per row (GenerativeUpBlock._topk_prediction,
+ * model/blocks.py:130-150, torch.topk).  Row i belongs to batch coords[i*4]; batch b keeps
+ * its k[b] largest logits (logits[i*ld]); exact ties are broken by ascending voxel key.
+ * NaN sorts above +inf (torch.topk).  state: >= pcc_topk_state_elems(nbatch) int32 elements.
+ * ------------------------------------------------------------------------------------- */
+int64_t pcc_topk_state_elems(int32_t nbatch);
+int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_t n, int32_t nbatch,
+                  const int32_t* k, uint8_t* mask, int32_t* state, void* stream);
+
+/* rows-per-batch histogram (AnalysisTransform.count_per_batch, model/transforms.py:65-71). */
+int pcc_count_per_batch(const int32_t* coords, int64_t n, int32_t nbatch, int32_t* counts, void* stream);
+
+/* Canonical (b,x,y,z)-lexicographic order (utils.sort_tensor / sort_points,
+ * utils.py:155-204): perm[r] = input row that comes r-th.  scratch_bytes from the query. */
+int64_t pcc_sort_scratch_bytes(int64_t n);
+int pcc_sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* scratch,
+                    int64_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Entropy model, device side (compressai EntropyBottleneck / GaussianConditional,
+ * model/entropy_models.py:313,330,352-353,371-372,393,407-408).  Features are [N, C]
+ * row-major; symbol / index / likelihood planes are channel-major [C, N] — the order in
+ * which the reference flattens (1, C, N) tensors into one rANS stream.
+ * ------------------------------------------------------------------------------------- */
+/* symbols[c,n] = rint(z[n,c] - median[c]);  z_hat[n,c] = symbols + median  (either may be NULL). */
+int pcc_eb_quantize(const float* z, int64_t n, int32_t c, const float* medians, int32_t* symbols,
+                    float* z_hat, void* stream);
+/* z_hat[n,c] = symbols[c,n] + median[c] */
+int pcc_eb_dequantize(const int32_t* symbols, int64_t n, int32_t c, const float* medians,
+                      float* z_hat, void* stream);
+/* Factorized-density likelihood max(|sigmoid(s*u) - sigmoid(s*l)|, 1e-9) of v = z_hat
+ * (B.2).  eb_params: per channel 58 floats = softplus(matrix_i), bias_i, tanh(factor_i)
+ * flattened in the order m0[3] b0[3] f0[3] m1[9] b1[3] f1[3] m2[9] b2[3] f2[3] m3[9] b3[3]
+ * f3[3] m4[3] b4[1].  lik is [C, N]. */
+int pcc_eb_likelihood(const float* z_hat, int64_t n, int32_t c, const float* eb_params, float* lik,
+                      void* stream);
+/* params [N, 2C] = (scales | means) rows aligned with y (h_s output looked up at y's
+ * coordinates).  indexes[c,n] = 63-level table index of max(scale, 0.11);
+ * symbols[c,n] = rint(y - mean).  scale_table: `levels` ascending floats. */
+int pcc_gc_encode_prep(const float* y, const float* params, int64_t n, int32_t c,
+                       const float* scale_table, int32_t levels, int32_t* symbols,
+                       int32_t* indexes, void* stream);
+/* y_hat[n,c] = symbols[c,n] + mean[n,c]  (GaussianConditional.decompress/dequantize). */
+int pcc_gc_dequantize(const int32_t* symbols, const float* params, int64_t n, int32_t c, float* y_hat,
+                      void* stream);
+/* eval-mode forward: y_hat = rint(y - mean) + mean, lik[c,n] = Gaussian bin mass, floor 1e-9. */
+int pcc_gc_forward(const float* y, const float* params, int64_t n, int32_t c, float* y_hat, float* lik,
+                   void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Entropy coder, host side (compressai _CXX / ans: encode_with_indexes,
+ * decode_with_indexes, pmf_to_quantized_cdf — same argument order).  All pointers HOST.
+ * cdfs is [n_cdfs, cdf_stride] int32.  One rANS stream per call.
+ * ------------------------------------------------------------------------------------- */
+/* Returns bytes written (>= 8), PCC_ERR_ARG if out_cap is too small (needs <= 4*(3n+4)). */
+int64_t pcc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n,
+                                     const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                     const int32_t* offsets, uint8_t* out, int64_t out_cap);
+int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
+                                 const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                 const int32_t* offsets, int32_t* out_symbols);
+/* cdf has n+1 entries. */
+int pcc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCC_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libpcc_hip.so (the C-ABI declared in include/pcc_hip.h).
+
+The library is built in-tree by ``build()`` (``make -C csrc``; hipcc --offload-arch=gfx950) and
+must be present for any operator call: there is no CPU fallback and no second backend.  A
+missing or unloadable library raises ``RuntimeError`` at first use.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libpcc_hip.so")
+_lib = None
+
+c_void_p, c_int, c_i32, c_i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64
+
+# name -> (restype, argtypes).  Kept in lock-step with include/pcc_hip.h (tests check every
+# symbol declared there is exported and listed here).
+SIGNATURES = {
+    "pcc_version": (c_int, []),
+    "pcc_last_error": (ctypes.c_char_p, []),
+    "pcc_device_count": (c_int, []),
+    "pcc_device_name": (c_int, [c_int, ctypes.c_char_p, c_int]),
+    "pcc_hash_capacity": (c_i64, [c_i64]),
+    "pcc_hash_build": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pcc_hash_lookup": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pcc_scan_scratch_elems": (c_i64, [c_i64]),
+    "pcc_stride_map": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_children": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_kernel_map": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_conv_packed_elems": (c_i64, [c_i32, c_i32, c_i32]),
+    "pcc_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
+    "pcc_conv_fwd": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+                             c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_gather_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_void_p]),
+    "pcc_scatter_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pcc_compact_rows": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_topk_state_elems": (c_i64, [c_i32]),
+    "pcc_topk_mask": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_count_per_batch": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "pcc_sort_scratch_bytes": (c_i64, [c_i64]),
+    "pcc_sort_coords": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_eb_quantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_eb_dequantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_eb_likelihood": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_gc_encode_prep": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_gc_dequantize": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "pcc_gc_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_rans_encode_with_indexes": (c_i64, [c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64]),
+    "pcc_rans_decode_with_indexes": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_pmf_to_quantized_cdf": (c_int, [c_void_p, c_i32, c_i32, c_void_p]),
+}
+
+
+def build(force=False):
+    """Compile libpcc_hip.so for gfx950 (cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", os.path.join(_HERE, "csrc"), "-j4"]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+def lib():
+    """The loaded library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the codec operators.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+class PccError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc < 0:
+        raise PccError(f"libpcc_hip: error {rc}: {lib().pcc_last_error().decode(errors='replace')}")
+    return rc
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor / numpy array, or NULL."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+def stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,149 @@
+"""Building blocks of the transforms: ScaledBlock, GenerativeUpBlock, ConditionEncoder.
+
+Same module tree and parameter names as /root/reference/model/blocks.py so
+that reference checkpoints load with ``strict=True``; the forward passes are re-organised around
+the fused HIP convolution (bias + FiLM + activation + residual in the epilogue, shared kernel
+maps, outputs evaluated only where the reference reads them).
+"""
+import torch
+import torch.nn as nn
+
+from . import sparse as sp
+from .sparse import (ACT_NONE, ACT_RELU, ConvChain, CoordMap, MinkowskiConvolution,
+                     MinkowskiGenerativeConvolutionTranspose, MinkowskiPruning, MinkowskiReLU, SparseTensor)
+
+
+class _NonNegativeParametrizer(nn.Module):
+    def __init__(self, minimum=0.0, reparam_offset=2 ** -18):
+        super().__init__()
+        pedestal = float(reparam_offset) ** 2
+        self.register_buffer("pedestal", torch.tensor([pedestal]))
+        self.lower_bound = _Bound((float(minimum) + pedestal) ** 0.5)
+
+
+class _Bound(nn.Module):
+    def __init__(self, bound):
+        super().__init__()
+        self.register_buffer("bound", torch.tensor([float(bound)]))
+
+
+class MinkowskiGDN(nn.Module):
+    """Parameter holder for the (inverse) GDN that the reference constructs in every ScaledBlock
+    (model/blocks.py:27) but never executes (its forward at :29-53 does not call it).  Kept so the
+    parameter count (31,469,942 <-> README.md:125) and state_dict keys match."""
+
+    def __init__(self, in_channels, inverse=False, beta_min=1e-6, gamma_init=0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = _NonNegativeParametrizer(minimum=beta_min)
+        self.gamma_reparam = _NonNegativeParametrizer()
+        ped = float(self.beta_reparam.pedestal)
+        self.beta = nn.Parameter(torch.sqrt(torch.clamp(torch.ones(in_channels) + ped, min=ped)))
+        self.gamma = nn.Parameter(torch.sqrt(torch.clamp(gamma_init * torch.eye(in_channels) + ped, min=ped)))
+
+
+def _conv(cin, cout, k=3, s=1, bias=True):
+    return MinkowskiConvolution(in_channels=cin, out_channels=cout, kernel_size=k, stride=s, bias=bias, dimension=3)
+
+
+class ScaledBlock(nn.Module):
+    """model/blocks.py:10-53: conv,ReLU,conv -> x*beta+gamma -> conv,ReLU,conv,ReLU -> + x."""
+
+    def __init__(self, N, encode=True, scale=True):
+        super().__init__()
+        self.encode, self.scale = encode, scale
+        self.conv_1 = ConvChain(_conv(N, N), MinkowskiReLU(), _conv(N, N))
+        self.conv_2 = ConvChain(_conv(N, N), MinkowskiReLU(), _conv(N, N), MinkowskiReLU())
+        self.gdn = MinkowskiGDN(N, inverse=(not encode))
+
+    def forward(self, x, condition):
+        """``condition``: SparseTensor of beta|gamma ([*, 2N]).  When it lives on x's coordinate map
+        its rows are already aligned and the FiLM is fused; otherwise it is looked up at x's
+        coordinates first (features_at_coordinates, blocks.py:37)."""
+        if condition.map is x.map:
+            film = condition.F
+        else:
+            film = condition.features_at_coordinates(x.C)
+        h = self.conv_1(x, last_film=film if self.scale else None)
+        return self.conv_2(h, last_residual=x.F)
+
+
+class GenerativeUpBlock(nn.Module):
+    """model/blocks.py:78-181."""
+
+    def __init__(self, N_in, N_out, predict=False, dense=True, condition_ablation=None):
+        super().__init__()
+        self.dense = dense
+        self.condition_ablation = condition_ablation
+        self.conv = MinkowskiGenerativeConvolutionTranspose(in_channels=N_in, out_channels=N_out, kernel_size=3,
+                                                            stride=2, bias=True, dimension=3)
+        self.conv_2 = ConvChain(_conv(N_out, N_out), MinkowskiReLU(), _conv(N_out, N_out))
+        self.prune = MinkowskiPruning()
+        self.predict = predict
+        if predict:
+            self.occ_predict = ConvChain(_conv(N_out, N_out), MinkowskiReLU(), _conv(N_out, N_out))
+
+    def forward(self, x, coords=None, k=None, full_predictions=False):
+        if not self.predict:
+            return self._follow(x, coords)
+        if not self.dense or self.condition_ablation is not None:
+            raise NotImplementedError("dense=False / condition_ablation variants are outside BASELINE scope")
+        x = self.conv(x)                                   # genConvT k3 s2 -> all candidates
+        x = self.conv_2(x)
+        # only channel 0 of the occupancy head is ever read (blocks.py:142): evaluate just that
+        # column unless the caller wants the full tensor (training losses).
+        pred = self.occ_predict(x, last_out_channels=None if full_predictions else 1)
+        nb = x.map._nbatch if x.map._nbatch is not None else x.map.nbatch
+        mask = sp.topk_mask(pred.F, pred.C, k, nb)
+        coords_kept, feats_kept, _, _ = sp.compact_rows(mask, x.C, x.F)
+        up_map = CoordMap(coords_kept, x.map.stride, nbatch=x.map._nbatch)
+        return SparseTensor(feats_kept, coordinate_map=up_map), pred, up_map
+
+    def _follow(self, Q, up_map):
+        """predict=False (q_up_i, blocks.py:179-181): genConvT then prune to the kept coordinates.
+        Evaluated directly at the kept coordinates (same values, no candidate rows materialised);
+        the result lives on ``up_map`` so it stays row-aligned with the main branch."""
+        if not isinstance(up_map, CoordMap):
+            up_map = CoordMap(sp._as_int_coords(up_map), Q.map.stride // 2, nbatch=Q.map._nbatch)
+        return self.conv(Q, out_map=up_map)
+
+
+class ConditionEncoder(nn.Module):
+    """model/blocks.py:185-251 (conv_layers are constructed but never run: blocks.py:241)."""
+
+    def __init__(self, C_in, N_scales, N_features, condition_ablation=None):
+        super().__init__()
+        self.num_stages = len(N_scales)
+        self.condition_ablation = condition_ablation
+        self.pre_conv = ConvChain(_conv(C_in, N_features[0]), MinkowskiReLU())
+        self.conv_layers = nn.ModuleList()
+        self.predict_layers = nn.ModuleList()
+        self.down_layers = nn.ModuleList()
+        for i in range(self.num_stages):
+            down = _conv(N_features[i], N_features[i + 1], 3, 2)
+            self.down_layers.append(down)
+            self._register_layers(down, f"down_layers_{i}")
+            conv = ConvChain(_conv(N_features[i + 1], N_features[i + 1]), MinkowskiReLU(),
+                             _conv(N_features[i + 1], N_features[i + 1]))
+            self.conv_layers.append(conv)
+            self._register_layers(conv, f"conv_layers_{i}")
+            pred = ConvChain(_conv(N_features[i + 1], N_scales[i]), MinkowskiReLU(),
+                             _conv(N_scales[i], N_scales[i], 1), MinkowskiReLU(),
+                             _conv(N_scales[i], N_scales[i] * 2))
+            self.predict_layers.append(pred)
+            self._register_layers(pred, f"predict_layers_{i}")
+
+    def _register_layers(self, layer, name):
+        # the reference re-registers every parameter under a flat alias (blocks.py:228-231)
+        for pid, param in layer.named_parameters():
+            self.register_parameter(f"{name}_{pid}".replace(".", "_"), param)
+
+    def forward(self, Q):
+        if self.condition_ablation is not None:
+            raise NotImplementedError("condition_ablation is outside BASELINE scope (configs/Ours.yaml)")
+        Q = self.pre_conv(Q)
+        beta_gammas = []
+        for i in range(self.num_stages):
+            Q = self.down_layers[i](Q)
+            beta_gammas.append(self.predict_layers[i](Q))
+        return Q, beta_gammas

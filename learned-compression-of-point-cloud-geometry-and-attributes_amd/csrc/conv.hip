@@ -1,0 +1,357 @@
+// Sparse convolution forward for gfx950.
+//
+// Output-stationary implicit GEMM: a workgroup owns 128 output rows x BN output channels and
+// walks the kernel offsets k (in ascending order) and the input channels in chunks of 32.  For each
+// (k, chunk) it gathers the 128 neighbour rows' 128-byte slices into LDS (zero for absent
+// neighbours), stages the matching 32 x BN weight slab, and feeds fp32 MFMA
+// (v_mfma_f32_32x32x2_f32; exact fp32, SURVEY.md §7 "fp32 parity budget").  Accumulation order per
+// output element is fixed (k ascending, channel ascending inside the MFMA chain), so a result
+// depends only on the element's own neighbourhood — never on row order, tile placement or
+// arrival order.  That is what lets encoder and decoder reproduce h_s bit-exactly
+// (the job of the reference's Sorted* shims, model/entropy_models.py:12-102).
+//
+// Offsets with no neighbour anywhere in a 64-row group are skipped (group masks from
+// pcc_kernel_map): adding an all-zero product is exact, so skipping does not change results.
+//
+// Roofline: MFMA fp32 (157 TFLOP/s); algorithmic FLOPs per launch = 2 * pairs * cin * cout.
+#include "common.h"
+
+namespace pcc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* fin;
+    const float* w;       // raw [K, cin, cout] (thin path)
+    const float* wp;      // packed [K, cinp/4, coutp, 4] (MFMA path)
+    const float* bias;    // [cout] or null
+    const int32_t* nbr;   // [n_out, K] or null (identity)
+    const uint32_t* gmask;  // [ceil(n_out/64)] or null (all offsets active)
+    float* fout;
+    const float* film;      // [n_out, 2*cout] or null
+    const float* residual;  // [n_out, cout] or null
+    int64_t n_in, n_out;
+    int cin, cout, coutp, K, act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == PCC_ACT_RELU) return v > 0.0f ? v : 0.0f;
+    if (act == PCC_ACT_LEAKY_RELU) return v > 0.0f ? v : 0.01f * v;
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: Wp[k][g][col][s] = W[k][4g+s][col], zero padded to cinp (x32) and coutp (x32)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, int K, int cin, int cout,
+                                                           int cinp, int coutp, float* __restrict__ wp) {
+    const int64_t total = (int64_t)K * cinp * coutp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int s = (int)(e & 3);
+        int64_t t = e >> 2;
+        const int col = (int)(t % coutp);
+        t /= coutp;
+        const int g = (int)(t % (cinp / 4));
+        const int k = (int)(t / (cinp / 4));
+        const int ci = 4 * g + s;
+        wp[e] = (ci < cin && col < cout) ? w[((int64_t)k * cin + ci) * cout + col] : 0.0f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA path
+// ---------------------------------------------------------------------------------------------
+constexpr int BM = 128;
+constexpr int A_LD = 36;             // floats per LDS row: 32 + 4 pad -> conflict-free ds_read_b128
+constexpr int A_ELEMS = BM * A_LD;   // per buffer
+
+template <int BN>
+constexpr int conv_lds_bytes() { return 2 * (A_ELEMS + 8 * BN * 4) * (int)sizeof(float); }
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int W_ELEMS = 8 * BN * 4;
+    constexpr int W_LOADS = (8 * BN) / 256;  // float4 per thread per chunk
+    static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1 && W_LOADS >= 1, "bad tiling");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Ws = smem + 2 * A_ELEMS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wrow = (wid / WAVES_N) * WM, wcol = (wid % WAVES_N) * WN;
+
+    const int ntiles_n = a.coutp / BN;
+    const int64_t tile = blockIdx.x / ntiles_n;
+    const int nt = blockIdx.x - (int)(tile * ntiles_n);
+    const int64_t row0 = tile * BM;
+    const int CCH = a.cin / 32;
+    const int K = a.K;
+
+    // which kernel offsets are live for this tile / for this wave's rows
+    uint32_t tmask, wmask;
+    {
+        const uint32_t all = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+        if (a.gmask) {
+            const int64_t g0 = row0 >> 6;
+            const int64_t ng = (a.n_out + 63) >> 6;
+            const uint32_t m0 = a.gmask[g0] & all;
+            const uint32_t m1 = (g0 + 1 < ng) ? (a.gmask[g0 + 1] & all) : 0u;
+            tmask = m0 | m1;
+            if (WM == 64) wmask = (wrow == 0) ? m0 : m1;
+            else wmask = (wrow < 64) ? m0 : m1;
+        } else {
+            tmask = wmask = all;
+        }
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+
+    // gather roles: 8 lanes per row (16 B each), 32 rows per pass, 4 passes
+    const int grow = t >> 3, gchunk = t & 7;
+    int idx_cur[4], idx_nxt[4];
+    f32x4 areg[4];
+    f32x4 wreg[W_LOADS];
+
+    auto load_idx = [&](int k, int (&dst)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t row = row0 + grow + 32 * i;
+            int v = -1;
+            if (row < a.n_out) v = a.nbr ? a.nbr[row * K + k] : (int)row;
+            dst[i] = v;
+        }
+    };
+    auto load_step = [&](int k, int c, const int (&idx)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx[i] >= 0) v = *reinterpret_cast<const f32x4*>(a.fin + (int64_t)idx[i] * a.cin + c * 32 + gchunk * 4);
+            areg[i] = v;
+        }
+        const float* wbase = a.wp + (((int64_t)k * (a.cin / 4) + c * 8) * a.coutp + nt * BN) * 4;
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) {
+            const int f = t + 256 * j;
+            const int g = f / BN, col = f - g * BN;
+            wreg[j] = *reinterpret_cast<const f32x4*>(wbase + ((int64_t)g * a.coutp + col) * 4);
+        }
+    };
+    auto store_step = [&](int buf) {
+        float* Ab = As + buf * A_ELEMS;
+        float* Wb = Ws + buf * W_ELEMS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ab + (grow + 32 * i) * A_LD + gchunk * 4) = areg[i];
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<f32x4*>(Wb + (t + 256 * j) * 4) = wreg[j];
+    };
+    auto compute = [&](int buf) {
+        const float* Ab = As + buf * A_ELEMS;
+        const float* Wb = Ws + buf * W_ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 av[MT], bv[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                av[m] = *reinterpret_cast<const f32x4*>(Ab + (wrow + 32 * m + r) * A_LD + 8 * kk + 4 * h);
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                bv[n] = *reinterpret_cast<const f32x4*>(Wb + ((2 * kk + h) * BN + wcol + 32 * n + r) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+        }
+    };
+
+    if (tmask != 0u) {
+        uint32_t rem = tmask;
+        int k = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        int knext = rem ? __builtin_ctz(rem) : -1;
+        load_idx(k, idx_cur);
+        load_step(k, 0, idx_cur);
+        store_step(0);
+        if (knext >= 0) load_idx(knext, idx_nxt);
+        __syncthreads();
+        int c = 0, cur = 0;
+        while (true) {
+            int nk = k, nc = c + 1;
+            if (nc == CCH) { nc = 0; nk = knext; }
+            const bool has_next = nk >= 0;
+            if (has_next) {
+                if (nc == 0) load_step(nk, 0, idx_nxt);
+                else load_step(nk, nc, idx_cur);
+            }
+            if ((wmask >> k) & 1u) compute(cur);
+            if (has_next) store_step(cur ^ 1);
+            __syncthreads();
+            if (!has_next) break;
+            if (nc == 0) {
+                k = nk;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) idx_cur[i] = idx_nxt[i];
+                rem &= rem - 1u;
+                knext = rem ? __builtin_ctz(rem) : -1;
+                if (knext >= 0) load_idx(knext, idx_nxt);
+            }
+            c = nc;
+            cur ^= 1;
+        }
+    }
+
+    // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r] per 32x32 tile
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = nt * BN + wcol + 32 * n + r;
+            if (col >= a.cout) continue;
+            const float bcol = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t row = row0 + wrow + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (row >= a.n_out) continue;
+                float v = acc[m][n][reg] + bcol;
+                if (a.film) {
+                    const float* fr = a.film + row * (2 * (int64_t)a.cout);
+                    v = v * fr[col] + fr[a.cout + col];
+                }
+                v = apply_act(v, a.act);
+                if (a.residual) v += a.residual[row * a.cout + col];
+                a.fout[row * a.cout + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// thin path: cin <= 16 (q-map branches, input layers).  HBM/latency bound; W lives in LDS.
+// One thread per (row, output channel); the gathered inputs are broadcast across the row's lanes.
+// ---------------------------------------------------------------------------------------------
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int K = a.K, cout = a.cout;
+    const int wtotal = K * CIN * cout;
+    for (int e = threadIdx.x; e < wtotal; e += 256) smem[e] = a.w[e];
+    __syncthreads();
+    const int64_t total = a.n_out * cout;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / cout;
+        const int co = (int)(e - row * cout);
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const int idx = a.nbr ? a.nbr[row * K + k] : (int)row;
+            if (idx < 0) continue;
+            const float* src = a.fin + (int64_t)idx * CIN;
+            const float* wk = smem + (k * CIN) * cout + co;
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) acc = fmaf(src[ci], wk[ci * cout], acc);
+        }
+        float v = acc + (a.bias ? a.bias[co] : 0.0f);
+        if (a.film) {
+            const float* fr = a.film + row * (2 * (int64_t)cout);
+            v = v * fr[co] + fr[cout + co];
+        }
+        v = apply_act(v, a.act);
+        if (a.residual) v += a.residual[e];
+        a.fout[e] = v;
+    }
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+static int launch_mfma(const ConvArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv_mfma_kernel<BN, WAVES_M, WAVES_N>;
+    constexpr int lds = conv_lds_bytes<BN>();
+    if (!attr_set) {
+        PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int64_t tiles = (a.n_out + BM - 1) / BM;
+    const int64_t blocks = tiles * (a.coutp / BN);
+    PCC_REQUIRE(blocks < (1ll << 31), "conv: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+template <int CIN>
+static int launch_thin(const ConvArgs& a, hipStream_t st) {
+    const size_t lds = (size_t)a.K * CIN * a.cout * sizeof(float);
+    PCC_REQUIRE(lds <= 64 * 1024, "conv(thin): weights %zu B exceed LDS budget (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
+    const int64_t total = a.n_out * a.cout;
+    hipLaunchKernelGGL(conv_thin_kernel<CIN>, dim3(blocks_for(total, 256, 1 << 20)), dim3(256), lds, st, a);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+}  // namespace pcc
+
+using namespace pcc;
+
+static inline int round_up32(int v) { return (v + 31) / 32 * 32; }
+
+extern "C" {
+
+int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout) {
+    return (int64_t)K * round_up32(cin) * round_up32(cout);
+}
+
+int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, float* w_packed, void* stream) {
+    PCC_REQUIRE(K >= 1 && cin >= 1 && cout >= 1, "pcc_conv_pack_weights: bad shape");
+    const int cinp = round_up32(cin), coutp = round_up32(cout);
+    const int64_t total = (int64_t)K * cinp * coutp;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), w, K, cin,
+                       cout, cinp, coutp, w_packed);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
+                 const int32_t* nbr, const uint32_t* group_mask, int32_t K, float* fout, int64_t n_out, int32_t cout,
+                 int32_t act, const float* film, const float* residual, void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd: K=%d out of range", K);
+    PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd: nbr == NULL needs K == 1 and n_in == n_out");
+    PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation %d", act);
+    if (n_out <= 0) return PCC_OK;
+    ConvArgs a;
+    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.gmask = group_mask; a.fout = fout;
+    a.film = film; a.residual = residual; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout;
+    a.coutp = round_up32(cout); a.K = K; a.act = act;
+    hipStream_t st = as_stream(stream);
+    if (cin % 32 == 0) {
+        PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd: MFMA path (cin=%d) needs packed weights", cin);
+        if (a.coutp % 128 == 0) return launch_mfma<128, 2, 2>(a, st);
+        if (a.coutp % 64 == 0) return launch_mfma<64, 2, 2>(a, st);
+        return launch_mfma<32, 4, 1>(a, st);
+    }
+    PCC_REQUIRE(w != nullptr, "pcc_conv_fwd: thin path (cin=%d) needs raw weights", cin);
+    switch (cin) {
+        case 1: return launch_thin<1>(a, st);
+        case 2: return launch_thin<2>(a, st);
+        case 4: return launch_thin<4>(a, st);
+        case 8: return launch_thin<8>(a, st);
+        case 16: return launch_thin<16>(a, st);
+        default:
+            pcc::set_error("pcc_conv_fwd: unsupported cin=%d (need a multiple of 32 or one of 1,2,4,8,16)", cin);
+            return PCC_ERR_UNSUPPORTED;
+    }
+}
+
+}  // extern "C"

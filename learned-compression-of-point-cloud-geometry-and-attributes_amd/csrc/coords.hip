@@ -1,0 +1,528 @@
+// Coordinate manager kernels: hashed-voxel table, stride map, generative children,
+// kernel (neighbour) map, prefix scan, pruning, row gather/scatter.
+//
+// All of this is HBM-/atomic-bound integer work: the design
+// rules that matter are coalesced candidate streams, one 64-bit CAS per insert, and keeping
+// results independent of thread arrival order (the winner of a duplicate is the smallest
+// candidate index, so outputs are bit-reproducible).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.h"
+
+namespace pcc {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan of int32 flags: 3 kernels, 1024 items per 256-thread block
+// ---------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 4;
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// returns exclusive prefix of v within the block; total in *block_total (all threads)
+__device__ __forceinline__ int block_exclusive_scan(int v, int* block_total) {
+    __shared__ int wave_sums[SCAN_BLOCK / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) wave_sums[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+        const int s = wave_sums[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *block_total = tot;
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_block_sums(const int32_t* __restrict__ flags, int64_t m,
+                                                              int32_t* __restrict__ block_sums) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (base + i < m) v += flags[base + i];
+    int tot;
+    block_exclusive_scan(v, &tot);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_of_block_sums(int32_t* __restrict__ block_sums, int64_t nb,
+                                                                 int64_t* __restrict__ total_out) {
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < nb; base += SCAN_BLOCK) {
+        const int64_t i = base + threadIdx.x;
+        const int v = (i < nb) ? block_sums[i] : 0;
+        int tot;
+        const int ex = block_exclusive_scan(v, &tot);
+        const int carry = carry_s;
+        if (i < nb) block_sums[i] = carry + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total_out) *total_out = (int64_t)carry_s;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const int32_t* __restrict__ flags, int64_t m,
+                                                         const int32_t* __restrict__ block_offsets,
+                                                         int32_t* __restrict__ pos) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+    int f[SCAN_ITEMS];
+    int v = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        f[i] = (base + i < m) ? flags[base + i] : 0;
+        v += f[i];
+    }
+    int tot;
+    int ex = block_exclusive_scan(v, &tot) + block_offsets[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < m) pos[base + i] = ex;
+        ex += f[i];
+    }
+}
+
+// flags and pos may alias (in-place).  block_sums: ceil(m / SCAN_TILE) ints.
+static int exclusive_scan(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total,
+                          hipStream_t st) {
+    const int64_t nb = (m + SCAN_TILE - 1) / SCAN_TILE;
+    if (m <= 0) {
+        return hipMemsetAsync(total, 0, sizeof(int64_t), st) == hipSuccess ? PCC_OK : PCC_ERR_HIP;
+    }
+    hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums);
+    hipLaunchKernelGGL(scan_of_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sums, nb, total);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums, pos);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hash table
+// ---------------------------------------------------------------------------------------------
+__global__ void table_clear(uint64_t* __restrict__ keys, int32_t* __restrict__ vals, int64_t cap) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+        keys[i] = KEY_EMPTY;
+        vals[i] = 0x7fffffff;
+    }
+}
+
+// claim (or find) the slot of `key`; returns slot index
+__device__ __forceinline__ uint64_t table_claim(uint64_t* keys, uint64_t mask, uint64_t key) {
+    uint64_t slot = hash_key(key) & mask;
+    for (uint64_t probe = 0; probe <= mask; ++probe) {
+        uint64_t cur = keys[slot];
+        if (cur == KEY_EMPTY) {
+            cur = (uint64_t)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)KEY_EMPTY,
+                                      (unsigned long long)key);
+            if (cur == KEY_EMPTY) return slot;
+        }
+        if (cur == key) return slot;
+        slot = (slot + 1) & mask;
+    }
+    return mask + 1;  // table full: cannot happen with cap >= 2 * candidates
+}
+
+// Candidate generators ------------------------------------------------------------------------
+struct GenRows {  // candidate i = row i
+    const int32_t* coords;
+    __device__ __forceinline__ void get(int64_t i, int& b, int& x, int& y, int& z) const {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        b = c.x; x = c.y; y = c.z; z = c.w;
+    }
+};
+struct GenStride {  // candidate i = floor(row i / 2ts) * 2ts
+    const int32_t* coords;
+    int s2;  // 2 * ts (power of two in practice, but do a true floor division)
+    __device__ __forceinline__ int fl(int v) const {
+        int q = v / s2;
+        if ((v % s2) != 0 && v < 0) --q;
+        return q * s2;
+    }
+    __device__ __forceinline__ void get(int64_t i, int& b, int& x, int& y, int& z) const {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        b = c.x; x = fl(c.y); y = fl(c.z); z = fl(c.w);
+    }
+};
+struct GenChildren {  // ks=3: candidate i = (parent i / 27, offset i % 27); ks=2: (offset i / n, parent i % n)
+    const int32_t* coords;
+    int64_t n;
+    int ks, half;
+    __device__ __forceinline__ void get(int64_t i, int& b, int& x, int& y, int& z) const {
+        int64_t p;
+        int k;
+        if (ks == 3) { p = i / 27; k = (int)(i - p * 27); }
+        else { k = (int)(i / n); p = i - (int64_t)k * n; }
+        const int4 c = reinterpret_cast<const int4*>(coords)[p];
+        int dx, dy, dz;
+        kernel_offset(ks, k, dx, dy, dz);
+        b = c.x; x = c.y + dx * half; y = c.z + dy * half; z = c.w + dz * half;
+    }
+};
+
+template <class Gen>
+__global__ __launch_bounds__(256) void unique_insert(Gen gen, int64_t m, uint64_t* __restrict__ keys,
+                                                     int32_t* __restrict__ vals, uint64_t mask,
+                                                     int32_t* __restrict__ slot_of) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    int b, x, y, z;
+    gen.get(i, b, x, y, z);
+    const uint64_t slot = table_claim(keys, mask, pack_key(b, x, y, z));
+    slot_of[i] = (int32_t)slot;
+    if (slot <= mask) atomicMin(&vals[slot], (int32_t)i);
+}
+
+__global__ __launch_bounds__(256) void unique_flag(int64_t m, const int32_t* __restrict__ vals,
+                                                   const int32_t* __restrict__ slot_of, int32_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    flags[i] = (vals[slot_of[i]] == (int32_t)i) ? 1 : 0;
+}
+
+template <class Gen>
+__global__ __launch_bounds__(256) void unique_finalize(Gen gen, int64_t m, int32_t* __restrict__ vals,
+                                                       const int32_t* __restrict__ slot_of,
+                                                       const int32_t* __restrict__ pos,
+                                                       int32_t* __restrict__ out_coords) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int32_t slot = slot_of[i];
+    // winner test must not read vals after another winner rewrote it: winners own distinct slots,
+    // and a loser's candidate index can never equal a winner's compacted position *and* lose,
+    // so test against the flag implied by the scan instead: pos[i+1] - pos[i] is unavailable for the
+    // last element, hence recompute from vals only for slots not yet finalised (vals >= 0 always).
+    // To stay race-free we use a negative encoding: finalised slots hold -(row+1).
+    const int32_t v = vals[slot];
+    if (v == (int32_t)i) {
+        const int32_t row = pos[i];
+        int b, x, y, z;
+        gen.get(i, b, x, y, z);
+        reinterpret_cast<int4*>(out_coords)[row] = make_int4(b, x, y, z);
+        vals[slot] = -(row + 1);
+    }
+}
+
+__global__ void table_decode_vals(int32_t* __restrict__ vals, int64_t cap) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = vals[i];
+        if (v < 0) vals[i] = -v - 1;
+    }
+}
+
+template <class Gen>
+static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* scratch,
+                         int32_t* out_coords, int64_t* out_count, hipStream_t st) {
+    PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "hash capacity %lld is not a power of two", (long long)cap);
+    PCC_REQUIRE(cap >= 2 * m, "hash capacity %lld too small for %lld candidates", (long long)cap, (long long)m);
+    PCC_REQUIRE(m < (1ll << 31) - 1, "too many candidates (%lld)", (long long)m);
+    hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap);
+    if (m <= 0) {
+        PCC_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int64_t), st));
+        return PCC_OK;
+    }
+    int32_t* slot_of = scratch;
+    int32_t* flags = scratch + m;
+    int32_t* block_sums = scratch + 2 * m;
+    const unsigned nb = blocks_for(m, 256);
+    hipLaunchKernelGGL(unique_insert<Gen>, dim3(nb), dim3(256), 0, st, gen, m, keys, vals, (uint64_t)(cap - 1), slot_of);
+    hipLaunchKernelGGL(unique_flag, dim3(nb), dim3(256), 0, st, m, vals, slot_of, flags);
+    int rc = exclusive_scan(flags, m, flags, block_sums, out_count, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(unique_finalize<Gen>, dim3(nb), dim3(256), 0, st, gen, m, vals, slot_of, flags, out_coords);
+    hipLaunchKernelGGL(table_decode_vals, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, vals, cap);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void build_insert(const int32_t* __restrict__ coords, int64_t n,
+                                                    uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                                    uint64_t mask) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const uint64_t slot = table_claim(keys, mask, pack_key(c.x, c.y, c.z, c.w));
+    if (slot <= mask) atomicMin(&vals[slot], (int32_t)i);
+}
+
+__global__ __launch_bounds__(256) void build_count_dups(const int32_t* __restrict__ coords, int64_t n,
+                                                        const uint64_t* __restrict__ keys,
+                                                        const int32_t* __restrict__ vals, uint64_t mask,
+                                                        int32_t* __restrict__ dup_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    if (table_find(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w)) != (int32_t)i) atomicAdd(dup_count, 1);
+}
+
+__global__ __launch_bounds__(256) void lookup_kernel(const uint64_t* __restrict__ keys,
+                                                     const int32_t* __restrict__ vals, uint64_t mask,
+                                                     const int32_t* __restrict__ query, int64_t nq,
+                                                     int32_t* __restrict__ out_idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const int4 c = reinterpret_cast<const int4*>(query)[i];
+    out_idx[i] = table_find(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w));
+}
+
+// One 256-thread block per group of 64 output rows: 64*K probes, coalesced nbr stores,
+// group mask reduced in LDS.
+__global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restrict__ out_coords, int64_t n_out,
+                                                         const uint64_t* __restrict__ keys,
+                                                         const int32_t* __restrict__ vals, uint64_t mask, int ks,
+                                                         int K, int step, int32_t* __restrict__ nbr,
+                                                         uint32_t* __restrict__ group_mask) {
+    __shared__ int4 rows[64];
+    __shared__ unsigned gm;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const int64_t r = row0 + threadIdx.x;
+        rows[threadIdx.x] = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
+    }
+    if (threadIdx.x == 0) gm = 0u;
+    __syncthreads();
+    unsigned mybits = 0u;
+    const int total = 64 * K;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int lr = e / K, k = e - lr * K;
+        const int64_t r = row0 + lr;
+        if (r >= n_out) break;
+        int dx, dy, dz;
+        kernel_offset(ks, k, dx, dy, dz);
+        const int4 c = rows[lr];
+        const int idx = table_find(keys, vals, mask, pack_key(c.x, c.y + dx * step, c.z + dy * step, c.w + dz * step));
+        nbr[r * K + k] = idx;
+        if (idx >= 0) mybits |= (1u << k);
+    }
+    if (mybits) atomicOr(&gm, mybits);
+    __syncthreads();
+    if (threadIdx.x == 0 && group_mask) group_mask[blockIdx.x] = gm;
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int c,
+                                                          const int32_t* __restrict__ idx, int64_t n,
+                                                          float* __restrict__ out, int accumulate) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c;
+        const int col = (int)(e - r * c);
+        const int32_t s = idx[r];
+        const float v = (s >= 0) ? src[(int64_t)s * c + col] : 0.0f;
+        out[e] = accumulate ? out[e] + v : v;
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, int c,
+                                                           const int32_t* __restrict__ idx, int64_t n,
+                                                           float* __restrict__ out) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c;
+        const int col = (int)(e - r * c);
+        const int32_t d = idx[r];
+        if (d >= 0) out[(int64_t)d * c + col] = src[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void mask_to_flags(const uint8_t* __restrict__ mask, int64_t n,
+                                                     int32_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = mask[i] ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void compact_index_kernel(const uint8_t* __restrict__ mask,
+                                                            const int32_t* __restrict__ pos, int64_t n,
+                                                            const int32_t* __restrict__ coords,
+                                                            int32_t* __restrict__ out_coords,
+                                                            int32_t* __restrict__ new_index) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool keep = mask[i] != 0;
+    const int32_t p = pos[i];
+    if (new_index) new_index[i] = keep ? p : -1;
+    if (keep && coords) reinterpret_cast<int4*>(out_coords)[p] = reinterpret_cast<const int4*>(coords)[i];
+}
+
+__global__ __launch_bounds__(256) void compact_feats_kernel(const uint8_t* __restrict__ mask,
+                                                            const int32_t* __restrict__ pos, int64_t n, int c,
+                                                            const float* __restrict__ feats,
+                                                            float* __restrict__ out_feats) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c;
+        if (mask[r]) out_feats[(int64_t)pos[r] * c + (e - r * c)] = feats[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void count_batch_kernel(const int32_t* __restrict__ coords, int64_t n, int nbatch,
+                                                          int32_t* __restrict__ counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = coords[i * 4];
+    if (b >= 0 && b < nbatch) atomicAdd(&counts[b], 1);
+}
+
+}  // namespace pcc
+
+using namespace pcc;
+
+extern "C" {
+
+int pcc_version(void) { return 1; }
+const char* pcc_last_error(void) { return pcc::last_error(); }
+
+int pcc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pcc_device_name(int dev, char* out, int out_len) {
+    hipDeviceProp_t p;
+    PCC_CHECK_HIP(hipGetDeviceProperties(&p, dev));
+    snprintf(out, (size_t)out_len, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return PCC_OK;
+}
+
+int64_t pcc_hash_capacity(int64_t n) {
+    int64_t cap = 1024;
+    while (cap < 2 * n) cap <<= 1;
+    return cap;
+}
+
+int64_t pcc_scan_scratch_elems(int64_t m) { return 2 * m + (m + SCAN_TILE - 1) / SCAN_TILE + 16; }
+
+int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* dup_count,
+                   void* stream) {
+    hipStream_t st = as_stream(stream);
+    PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0 && cap >= 2 * n, "pcc_hash_build: bad capacity %lld for n=%lld",
+                (long long)cap, (long long)n);
+    hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap);
+    if (dup_count) PCC_CHECK_HIP(hipMemsetAsync(dup_count, 0, sizeof(int32_t), st));
+    if (n > 0) {
+        hipLaunchKernelGGL(build_insert, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys, vals,
+                           (uint64_t)(cap - 1));
+        if (dup_count)
+            hipLaunchKernelGGL(build_count_dups, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys, vals,
+                               (uint64_t)(cap - 1), dup_count);
+    }
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_hash_lookup(const uint64_t* keys, const int32_t* vals, int64_t cap, const int32_t* query, int64_t nq,
+                    int32_t* out_idx, void* stream) {
+    PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "pcc_hash_lookup: bad capacity");
+    if (nq <= 0) return PCC_OK;
+    hipLaunchKernelGGL(lookup_kernel, dim3(blocks_for(nq, 256)), dim3(256), 0, as_stream(stream), keys, vals,
+                       (uint64_t)(cap - 1), query, nq, out_idx);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_stride_map(const int32_t* coords, int64_t n, int32_t ts, uint64_t* keys, int32_t* vals, int64_t cap,
+                   int32_t* scratch, int32_t* out_coords, int64_t* out_count, void* stream) {
+    PCC_REQUIRE(ts >= 1, "pcc_stride_map: tensor stride must be >= 1");
+    GenStride gen{coords, 2 * ts};
+    return unique_coords(gen, n, keys, vals, cap, scratch, out_coords, out_count, as_stream(stream));
+}
+
+int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, uint64_t* keys, int32_t* vals,
+                 int64_t cap, int32_t* scratch, int32_t* out_coords, int64_t* out_count, void* stream) {
+    PCC_REQUIRE(ksize == 2 || ksize == 3, "pcc_children: kernel size must be 2 or 3");
+    PCC_REQUIRE(ts >= 2 && (ts % 2) == 0, "pcc_children: tensor stride %d is not even", ts);
+    const int K = ksize * ksize * ksize;
+    GenChildren gen{coords, n, ksize, ts / 2};
+    return unique_coords(gen, n * K, keys, vals, cap, scratch, out_coords, out_count, as_stream(stream));
+}
+
+int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals,
+                   int64_t in_cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* group_mask,
+                   void* stream) {
+    PCC_REQUIRE(ksize >= 1 && ksize <= 3, "pcc_kernel_map: kernel size must be 1..3");
+    PCC_REQUIRE(sign == 1 || sign == -1, "pcc_kernel_map: sign must be +1/-1");
+    PCC_REQUIRE(in_cap > 0 && (in_cap & (in_cap - 1)) == 0, "pcc_kernel_map: bad capacity");
+    if (n_out <= 0) return PCC_OK;
+    const int K = ksize * ksize * ksize;
+    hipLaunchKernelGGL(kernel_map_kernel, dim3(blocks_for(n_out, 64)), dim3(256), 0, as_stream(stream), out_coords,
+                       n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), ksize, K, sign * step, nbr, group_mask);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_gather_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out, int32_t accumulate,
+                    void* stream) {
+    if (n <= 0 || c <= 0) return PCC_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for(n * c, 256, 65536)), dim3(256), 0, as_stream(stream), src, c,
+                       idx, n, out, accumulate);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_scatter_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out, void* stream) {
+    if (n <= 0 || c <= 0) return PCC_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks_for(n * c, 256, 65536)), dim3(256), 0, as_stream(stream), src,
+                       c, idx, n, out);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_compact_rows(const uint8_t* mask, int64_t n, const int32_t* coords, int32_t* out_coords, const float* feats,
+                     int32_t c, float* out_feats, int32_t* new_index, int32_t* scratch, int64_t* out_count,
+                     void* stream) {
+    hipStream_t st = as_stream(stream);
+    if (n <= 0) {
+        PCC_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int64_t), st));
+        return PCC_OK;
+    }
+    int32_t* flags = scratch;
+    int32_t* block_sums = scratch + n;
+    hipLaunchKernelGGL(mask_to_flags, dim3(blocks_for(n, 256)), dim3(256), 0, st, mask, n, flags);
+    int rc = exclusive_scan(flags, n, flags, block_sums, out_count, st);
+    if (rc) return rc;
+    if (coords || new_index)
+        hipLaunchKernelGGL(compact_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, mask, flags, n, coords,
+                           out_coords, new_index);
+    if (feats && c > 0)
+        hipLaunchKernelGGL(compact_feats_kernel, dim3(blocks_for(n * c, 256, 65536)), dim3(256), 0, st, mask, flags, n, c,
+                           feats, out_feats);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_count_per_batch(const int32_t* coords, int64_t n, int32_t nbatch, int32_t* counts, void* stream) {
+    hipStream_t st = as_stream(stream);
+    PCC_REQUIRE(nbatch >= 1, "pcc_count_per_batch: nbatch must be >= 1");
+    PCC_CHECK_HIP(hipMemsetAsync(counts, 0, sizeof(int32_t) * nbatch, st));
+    if (n > 0) hipLaunchKernelGGL(count_batch_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, nbatch, counts);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+}  // extern "C"

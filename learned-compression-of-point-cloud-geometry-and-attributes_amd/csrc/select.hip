@@ -1,0 +1,204 @@
+// Per-batch top-k occupancy selection (GenerativeUpBlock._topk_prediction, model/blocks.py:130-150)
+// and canonical coordinate sort (utils.sort_tensor / sort_points, utils.py:155-204).
+//
+// top-k = MSB-first radix select over a 96-bit composite key
+//     hi32 = order-preserving map of the fp32 logit (NaN on top, as torch.topk)
+//     lo64 = ~voxel_key   (exact logit ties -> ascending voxel key wins)
+// so the selected SET is a pure function of (logit, coordinate): independent of row order and
+// thread arrival order.  No host synchronisation: all passes are enqueued; a batch that has
+// resolved early turns the remaining passes into no-ops through its `done` word.
+// HBM-bound wavefront-level integer work, no dense contraction.
+#include <hipcub/hipcub.hpp>
+
+#include "common.h"
+
+namespace pcc {
+
+constexpr int TK_STRIDE = 264;  // int32 per batch: krem, done, nbytes, p0, p1, p2, pad, pad, hist[256]
+constexpr int TK_LDS_BATCHES = 16;
+
+__device__ __forceinline__ uint32_t float_key(float v) {
+    if (v != v) return 0xFFFFFFFFu;
+    if (v == 0.0f) v = 0.0f;  // -0 == +0
+    const uint32_t u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+struct Key96 { uint32_t w[3]; };
+
+__device__ __forceinline__ Key96 make_key(float logit, int4 c) {
+    const uint64_t lo = ~pack_key(c.x, c.y, c.z, c.w);
+    Key96 k;
+    k.w[0] = float_key(logit);
+    k.w[1] = (uint32_t)(lo >> 32);
+    k.w[2] = (uint32_t)lo;
+    return k;
+}
+
+__device__ __forceinline__ uint32_t top_bytes_mask(int nb, int word) {
+    int n = nb - 4 * word;
+    n = n < 0 ? 0 : (n > 4 ? 4 : n);
+    return n == 0 ? 0u : (0xFFFFFFFFu << (8 * (4 - n)));
+}
+
+// compare the top `nb` bytes of key with prefix: -1 / 0 / +1
+__device__ __forceinline__ int cmp_prefix(const Key96& k, const int32_t* st, int nb) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t m = top_bytes_mask(nb, j);
+        const uint32_t a = k.w[j] & m, b = (uint32_t)st[3 + j] & m;
+        if (a != b) return a > b ? 1 : -1;
+    }
+    return 0;
+}
+
+__global__ void topk_init(const int32_t* __restrict__ k, int nbatch, int32_t* __restrict__ state) {
+    const int b = blockIdx.x;
+    int32_t* st = state + (int64_t)b * TK_STRIDE;
+    for (int i = threadIdx.x; i < TK_STRIDE; i += blockDim.x) st[i] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int kk = k[b];
+        st[0] = kk;
+        if (kk <= 0) { st[1] = 1; st[2] = 13; }  // select nothing
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_hist(const float* __restrict__ logits, int ld,
+                                                 const int32_t* __restrict__ coords, int64_t n, int nbatch, int pass,
+                                                 int32_t* __restrict__ state) {
+    __shared__ int lh[TK_LDS_BATCHES * 256];
+    const bool use_lds = nbatch <= TK_LDS_BATCHES;
+    if (use_lds) {
+        for (int i = threadIdx.x; i < nbatch * 256; i += 256) lh[i] = 0;
+        __syncthreads();
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        const int b = c.x;
+        if (b < 0 || b >= nbatch) continue;
+        const int32_t* st = state + (int64_t)b * TK_STRIDE;
+        if (st[1]) continue;
+        const Key96 key = make_key(logits[i * ld], c);
+        if (cmp_prefix(key, st, pass) != 0) continue;
+        const uint32_t digit = (key.w[pass >> 2] >> (8 * (3 - (pass & 3)))) & 0xFFu;
+        if (use_lds) atomicAdd(&lh[b * 256 + digit], 1);
+        else atomicAdd(&state[(int64_t)b * TK_STRIDE + 8 + digit], 1);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nbatch * 256; i += 256) {
+            const int v = lh[i];
+            if (v) atomicAdd(&state[(int64_t)(i >> 8) * TK_STRIDE + 8 + (i & 255)], v);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_pick(int pass, int32_t* __restrict__ state) {
+    __shared__ int h[256];
+    __shared__ int total_s;
+    int32_t* st = state + (int64_t)blockIdx.x * TK_STRIDE;
+    const int d = threadIdx.x;
+    h[d] = st[8 + d];
+    __syncthreads();
+    // every thread reads the batch state before anyone rewrites it (writes come after the barrier)
+    const int done = st[1];
+    const int krem = st[0];
+    int above = 0;
+    for (int j = d + 1; j < 256; ++j) above += h[j];
+    if (d == 0) total_s = above + h[0];
+    __syncthreads();
+    st[8 + d] = 0;
+    if (done) return;
+    if (pass == 0 && total_s <= krem) {
+        // the batch has no more than k rows: keep them all (compare zero prefix bytes)
+        if (d == 0) { st[1] = 1; st[2] = 0; }
+        return;
+    }
+    // exactly one digit d satisfies this (its bucket holds the k-th largest key)
+    if (above < krem && krem <= above + h[d]) {
+        const int word = pass >> 2, shift = 8 * (3 - (pass & 3));
+        st[3 + word] = (int32_t)((uint32_t)st[3 + word] | ((uint32_t)d << shift));
+        const int knew = krem - above;
+        st[0] = knew;
+        if (h[d] == knew || pass == 11) { st[1] = 1; st[2] = pass + 1; }
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_write_mask(const float* __restrict__ logits, int ld,
+                                                       const int32_t* __restrict__ coords, int64_t n, int nbatch,
+                                                       const int32_t* __restrict__ state, uint8_t* __restrict__ mask) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const int b = c.x;
+    uint8_t m = 0;
+    if (b >= 0 && b < nbatch) {
+        const int32_t* st = state + (int64_t)b * TK_STRIDE;
+        const int nb = st[2];
+        if (nb <= 12) m = cmp_prefix(make_key(logits[i * ld], c), st, nb) >= 0 ? 1 : 0;
+    }
+    mask[i] = m;
+}
+
+__global__ __launch_bounds__(256) void coords_to_keys(const int32_t* __restrict__ coords, int64_t n,
+                                                      uint64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    keys[i] = pack_key(c.x, c.y, c.z, c.w);
+    iota[i] = (int32_t)i;
+}
+
+static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace pcc
+
+using namespace pcc;
+
+extern "C" {
+
+int64_t pcc_topk_state_elems(int32_t nbatch) { return (int64_t)nbatch * TK_STRIDE; }
+
+int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_t n, int32_t nbatch, const int32_t* k,
+                  uint8_t* mask, int32_t* state, void* stream) {
+    PCC_REQUIRE(nbatch >= 1 && nbatch < 32767, "pcc_topk_mask: bad nbatch %d", nbatch);
+    PCC_REQUIRE(ld >= 1, "pcc_topk_mask: bad leading dimension");
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(topk_init, dim3(nbatch), dim3(256), 0, st, k, nbatch, state);
+    if (n > 0) {
+        const unsigned nb = blocks_for(n, 256, 2048);
+        for (int pass = 0; pass < 12; ++pass) {
+            hipLaunchKernelGGL(topk_hist, dim3(nb), dim3(256), 0, st, logits, ld, coords, n, nbatch, pass, state);
+            hipLaunchKernelGGL(topk_pick, dim3(nbatch), dim3(256), 0, st, pass, state);
+        }
+        hipLaunchKernelGGL(topk_write_mask, dim3(blocks_for(n, 256)), dim3(256), 0, st, logits, ld, coords, n, nbatch,
+                           state, mask);
+    }
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int64_t pcc_sort_scratch_bytes(int64_t n) {
+    size_t temp = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+                                       (const int32_t*)nullptr, (int32_t*)nullptr, (int)(n > 0 ? n : 1));
+    return align256((int64_t)temp) + 2 * align256(n * 8) + align256(n * 4) + 256;
+}
+
+int pcc_sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (n <= 0) return PCC_OK;
+    PCC_REQUIRE(n < (1ll << 31), "pcc_sort_coords: too many rows");
+    PCC_REQUIRE(scratch_bytes >= pcc_sort_scratch_bytes(n), "pcc_sort_coords: scratch too small");
+    hipStream_t st = as_stream(stream);
+    char* p = reinterpret_cast<char*>(scratch);
+    uint64_t* keys_in = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
+    uint64_t* keys_out = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
+    int32_t* iota = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
+    size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
+    hipLaunchKernelGGL(coords_to_keys, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys_in, iota);
+    PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(p, temp, keys_in, keys_out, iota, perm, (int)n, 0, 64, st));
+    return PCC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,342 @@
+"""Factorized entropy bottleneck and Gaussian conditional on libpcc_hip.so.
+
+Host-side mirror of ``compressai.entropy_models.EntropyBottleneck`` / ``GaussianConditional``
+as the reference uses them (model/entropy_models.py:269-270,313,330,352-353,371-372,393,407-408):
+same constructor arguments, parameter / buffer names (so reference state_dicts load), and the
+``compress`` / ``decompress`` / ``forward`` / ``update`` / ``loss`` methods.  Quantisation, index
+build and likelihoods run as HIP kernels on [N, C] feature matrices; CDF tables are built on the
+host at ``update()`` (one-off) and the rANS coder is the host C++ one in the same library
+(SURVEY.md N12-N14).  Training-mode (additive noise, gradients) is not implemented.
+"""
+import math
+
+import numpy as np
+import scipy.stats
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr
+
+SCALES_MIN, SCALES_MAX, SCALES_LEVELS = 0.11, 256.0, 64
+
+
+def get_scale_table(minimum=SCALES_MIN, maximum=SCALES_MAX, levels=SCALES_LEVELS):
+    return torch.exp(torch.linspace(math.log(minimum), math.log(maximum), levels))
+
+
+class _LowerBound(nn.Module):
+    """Buffer holder matching compressai.ops.LowerBound's state_dict entry."""
+
+    def __init__(self, bound):
+        super().__init__()
+        self.register_buffer("bound", torch.tensor([float(bound)]))
+
+
+def _pmf_to_cdf(pmf, tail, pmf_length, max_length):
+    """compressai EntropyModel._pmf_to_cdf through the library's pmf_to_quantized_cdf."""
+    L = _lib.lib()
+    cdf = np.zeros((len(pmf_length), max_length + 2), dtype=np.int32)
+    for i in range(len(pmf_length)):
+        n = int(pmf_length[i])
+        prob = np.ascontiguousarray(np.concatenate([pmf[i, :n], tail[i].reshape(-1)]).astype(np.float32))
+        row = np.zeros(n + 2, dtype=np.int32)
+        check(L.pcc_pmf_to_quantized_cdf(ptr(prob), n + 1, 16, ptr(row)))
+        cdf[i, : n + 2] = row
+    return cdf
+
+
+def _rans_encode(symbols, indexes, cdf, cdf_length, offset):
+    """symbols / indexes: host int32 arrays (flattened channel-major)."""
+    L = _lib.lib()
+    symbols = np.ascontiguousarray(symbols, dtype=np.int32).reshape(-1)
+    indexes = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
+    n = symbols.size
+    cap = 4 * (3 * n + 4)
+    out = np.empty(cap, dtype=np.uint8)
+    nbytes = check(L.pcc_rans_encode_with_indexes(ptr(symbols), ptr(indexes), n, ptr(cdf), cdf.shape[1],
+                                                  ptr(cdf_length), ptr(offset), ptr(out), cap))
+    return out[:nbytes].tobytes()
+
+
+def _rans_decode(data, indexes, cdf, cdf_length, offset):
+    L = _lib.lib()
+    indexes = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
+    buf = np.frombuffer(data, dtype=np.uint8)
+    out = np.empty(indexes.size, dtype=np.int32)
+    check(L.pcc_rans_decode_with_indexes(ptr(buf), len(data), ptr(indexes), indexes.size, ptr(cdf), cdf.shape[1],
+                                         ptr(cdf_length), ptr(offset), ptr(out)))
+    return out
+
+
+class _EntropyModelBase(nn.Module):
+    def __init__(self, likelihood_bound=1e-9, entropy_coder_precision=16):
+        super().__init__()
+        self.entropy_coder_precision = int(entropy_coder_precision)
+        self.likelihood_lower_bound = _LowerBound(likelihood_bound)
+        self.register_buffer("_offset", torch.IntTensor())
+        self.register_buffer("_quantized_cdf", torch.IntTensor())
+        self.register_buffer("_cdf_length", torch.IntTensor())
+        self._host_tables = None
+
+    def _set_tables(self, cdf, cdf_length, offset):
+        dev = self._offset.device
+        self._quantized_cdf = torch.from_numpy(cdf).to(dev)
+        self._cdf_length = torch.from_numpy(cdf_length).to(dev)
+        self._offset = torch.from_numpy(offset).to(dev)
+        self._host_tables = (np.ascontiguousarray(cdf), np.ascontiguousarray(cdf_length), np.ascontiguousarray(offset))
+
+    def tables(self):
+        if self._host_tables is None:
+            if self._offset.numel() == 0:
+                raise RuntimeError("entropy tables missing: call update() before compress/decompress "
+                                   "(reference: evaluate.py:80-84)")
+            self._host_tables = (np.ascontiguousarray(self._quantized_cdf.cpu().numpy().astype(np.int32)),
+                                 np.ascontiguousarray(self._cdf_length.cpu().numpy().astype(np.int32)),
+                                 np.ascontiguousarray(self._offset.cpu().numpy().astype(np.int32)))
+        return self._host_tables
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # table buffers change size between a fresh module and an updated checkpoint
+        for name in ("_offset", "_quantized_cdf", "_cdf_length"):
+            key = prefix + name
+            if key in state_dict:
+                setattr(self, name, state_dict[key].clone().to(getattr(self, name).device))
+        self._host_tables = None
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class EntropyBottleneck(_EntropyModelBase):
+    """compressai EntropyBottleneck(channels, tail_mass=1e-9, init_scale=10, filters=(3,3,3,3))."""
+
+    def __init__(self, channels, tail_mass=1e-9, init_scale=10, filters=(3, 3, 3, 3)):
+        super().__init__()
+        self.channels = int(channels)
+        self.filters = tuple(int(f) for f in filters)
+        assert self.filters == (3, 3, 3, 3), "the HIP likelihood kernel is specialised for filters (3,3,3,3)"
+        self.init_scale = float(init_scale)
+        self.tail_mass = float(tail_mass)
+        f = (1,) + self.filters + (1,)
+        scale = self.init_scale ** (1 / (len(self.filters) + 1))
+        for i in range(len(self.filters) + 1):
+            init = np.log(np.expm1(1 / scale / f[i + 1]))
+            self.register_parameter(f"_matrix{i}", nn.Parameter(torch.full((channels, f[i + 1], f[i]), float(init))))
+            self.register_parameter(f"_bias{i}", nn.Parameter(torch.empty(channels, f[i + 1], 1).uniform_(-0.5, 0.5)))
+            if i < len(self.filters):
+                self.register_parameter(f"_factor{i}", nn.Parameter(torch.zeros(channels, f[i + 1], 1)))
+        self.quantiles = nn.Parameter(torch.tensor([-self.init_scale, 0.0, self.init_scale]).repeat(channels, 1, 1))
+        target = np.log(2 / self.tail_mass - 1)
+        self.register_buffer("target", torch.tensor([-target, 0.0, target], dtype=torch.float32))
+
+    # -- host math (used by update() and loss()) ---------------------------------------------
+    def _density_params(self, device=None):
+        get = lambda n: getattr(self, n) if device is None else getattr(self, n).detach().float().to(device)
+        return ([get(f"_matrix{i}") for i in range(5)], [get(f"_bias{i}") for i in range(5)],
+                [get(f"_factor{i}") for i in range(4)])
+
+    @staticmethod
+    def _logits_cumulative(params, v):
+        mats, biases, factors = params
+        for i in range(5):
+            v = torch.matmul(torch.nn.functional.softplus(mats[i]), v) + biases[i]
+            if i < 4:
+                v = v + torch.tanh(factors[i]) * torch.tanh(v)
+        return v
+
+    def loss(self):
+        """aux loss (reference: model/model.py:40-47, train.py:209)."""
+        logits = self._logits_cumulative(self._density_params(), self.quantiles)
+        return torch.abs(logits - self.target).sum()
+
+    def medians(self):
+        return self.quantiles[:, 0, 1].detach().contiguous()
+
+    @torch.no_grad()
+    def update(self, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        q = self.quantiles.detach().float().cpu()
+        cpu = self._density_params("cpu")   # host copy of the density parameters
+        med = q[:, 0, 1]
+        minima = torch.clamp(torch.ceil(med - q[:, 0, 0]).int(), min=0)
+        maxima = torch.clamp(torch.ceil(q[:, 0, 2] - med).int(), min=0)
+        pmf_start = med - minima
+        pmf_length = maxima + minima + 1
+        max_length = int(pmf_length.max())
+        samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+        lo = self._logits_cumulative(cpu, samples - 0.5)
+        up = self._logits_cumulative(cpu, samples + 0.5)
+        s = -torch.sign(lo + up)
+        pmf = torch.abs(torch.sigmoid(s * up) - torch.sigmoid(s * lo))[:, 0, :]
+        tail = torch.sigmoid(lo[:, 0, :1]) + torch.sigmoid(-up[:, 0, -1:])
+        cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+        self._set_tables(cdf, (pmf_length + 2).numpy().astype(np.int32), (-minima).numpy().astype(np.int32))
+        return True
+
+    # -- device side -----------------------------------------------------------------------------
+    def _kernel_params(self):
+        """[C, 58] = softplus(matrix_i) | bias_i | tanh(factor_i) flattened (see pcc_eb_likelihood)."""
+        parts = []
+        C = self.channels
+        for i in range(5):
+            parts.append(torch.nn.functional.softplus(getattr(self, f"_matrix{i}").detach()).reshape(C, -1))
+            parts.append(getattr(self, f"_bias{i}").detach().reshape(C, -1))
+            if i < 4:
+                parts.append(torch.tanh(getattr(self, f"_factor{i}").detach()).reshape(C, -1))
+        out = torch.cat(parts, dim=1).contiguous().float()
+        assert out.shape[1] == 58
+        return out
+
+    def quantize_features(self, z_feats, want_symbols=True, want_zhat=True):
+        """z_feats [N, C] -> (symbols int32 [C, N] | None, z_hat [N, C] | None)."""
+        n, c = z_feats.shape
+        dev = z_feats.device
+        sym = torch.empty((c, n), dtype=torch.int32, device=dev) if want_symbols else None
+        zhat = torch.empty((n, c), dtype=torch.float32, device=dev) if want_zhat else None
+        check(_lib.lib().pcc_eb_quantize(ptr(z_feats.contiguous()), n, c, ptr(self.medians()), ptr(sym), ptr(zhat),
+                                         _lib.stream()))
+        return sym, zhat
+
+    def likelihood_features(self, zhat_feats):
+        """z_hat [N, C] -> likelihood plane [C, N]."""
+        n, c = zhat_feats.shape
+        lik = torch.empty((c, n), dtype=torch.float32, device=zhat_feats.device)
+        check(_lib.lib().pcc_eb_likelihood(ptr(zhat_feats.contiguous()), n, c, ptr(self._kernel_params()), ptr(lik),
+                                           _lib.stream()))
+        return lik
+
+    def forward(self, x, training=None):
+        """x: (1, C, N) as in the reference (``z.F.t().unsqueeze(0)``); eval mode only."""
+        if self.training if training is None else training:
+            raise NotImplementedError("training-mode (noise) quantisation is outside this round's scope (SURVEY §8f)")
+        feats = x[0].t().contiguous()
+        _, zhat = self.quantize_features(feats, want_symbols=False)
+        lik = self.likelihood_features(zhat)
+        return zhat.t().unsqueeze(0), lik.unsqueeze(0)
+
+    def compress_features(self, z_feats, perm=None):
+        """-> ([bytes], z_hat [N, C]); symbol order = channel-major over rows (optionally permuted)."""
+        sym, zhat = self.quantize_features(z_feats)
+        if perm is not None:
+            sym = sym.index_select(1, perm.long())
+        cdf, cdf_len, off = self.tables()
+        c, n = sym.shape
+        idx = np.repeat(np.arange(c, dtype=np.int32), n)
+        return [_rans_encode(sym.cpu().numpy(), idx, cdf, cdf_len, off)], zhat
+
+    def compress(self, x):
+        strings, _ = self.compress_features(x[0].t().contiguous())
+        return strings
+
+    def decompress_features(self, strings, n, device):
+        """-> z_hat [N, C] on ``device``."""
+        cdf, cdf_len, off = self.tables()
+        c = self.channels
+        idx = np.repeat(np.arange(c, dtype=np.int32), n)
+        sym = torch.from_numpy(_rans_decode(strings[0], idx, cdf, cdf_len, off).reshape(c, n)).to(device)
+        zhat = torch.empty((n, c), dtype=torch.float32, device=device)
+        check(_lib.lib().pcc_eb_dequantize(ptr(sym), n, c, ptr(self.medians().to(device)), ptr(zhat), _lib.stream()))
+        return zhat
+
+    def decompress(self, strings, size):
+        n = int(size[0])
+        return self.decompress_features(strings, n, self.quantiles.device).t().unsqueeze(0)
+
+
+class GaussianConditional(_EntropyModelBase):
+    """compressai GaussianConditional(scale_table, scale_bound=0.11, tail_mass=1e-9)."""
+
+    def __init__(self, scale_table=None, scale_bound=0.11, tail_mass=1e-9):
+        super().__init__()
+        self.tail_mass = float(tail_mass)
+        self.lower_bound_scale = _LowerBound(scale_bound)
+        self.register_buffer("scale_table",
+                             torch.tensor([float(s) for s in scale_table]) if scale_table is not None else torch.Tensor())
+
+    @torch.no_grad()
+    def update_scale_table(self, scale_table, force=False):
+        if self._offset.numel() > 0 and not force:
+            return False
+        self.scale_table = torch.tensor([float(s) for s in scale_table], device=self.scale_table.device)
+        self.update()
+        return True
+
+    @torch.no_grad()
+    def update(self):
+        table = self.scale_table.detach().float().cpu()
+        mult = -scipy.stats.norm.ppf(self.tail_mass / 2)
+        center = torch.ceil(table * mult).int()
+        pmf_length = 2 * center + 1
+        max_length = int(pmf_length.max())
+        samples = torch.abs(torch.arange(max_length).int() - center[:, None]).float()
+        s = table[:, None]
+        Phi = lambda v: 0.5 * torch.erfc(-(2 ** -0.5) * v)
+        upper = Phi((0.5 - samples) / s)
+        lower = Phi((-0.5 - samples) / s)
+        pmf = upper - lower
+        tail = 2 * lower[:, :1]
+        cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+        self._set_tables(cdf, (pmf_length + 2).numpy().astype(np.int32), (-center).numpy().astype(np.int32))
+
+    # -- device side, [N, C] features; params [N, 2C] = (scales | means) aligned with y ------------
+    def encode_prep(self, y_feats, params):
+        n, c = y_feats.shape
+        dev = y_feats.device
+        sym = torch.empty((c, n), dtype=torch.int32, device=dev)
+        idx = torch.empty((c, n), dtype=torch.int32, device=dev)
+        table = self.scale_table.to(dev).contiguous()
+        check(_lib.lib().pcc_gc_encode_prep(ptr(y_feats.contiguous()), ptr(params.contiguous()), n, c, ptr(table),
+                                            table.numel(), ptr(sym), ptr(idx), _lib.stream()))
+        return sym, idx
+
+    def indexes_for(self, params, c):
+        n = params.shape[0]
+        dev = params.device
+        idx = torch.empty((c, n), dtype=torch.int32, device=dev)
+        table = self.scale_table.to(dev).contiguous()
+        check(_lib.lib().pcc_gc_encode_prep(None, ptr(params.contiguous()), n, c, ptr(table), table.numel(), None,
+                                            ptr(idx), _lib.stream()))
+        return idx
+
+    def compress_features(self, y_feats, params, perm=None):
+        sym, idx = self.encode_prep(y_feats, params)
+        if perm is not None:
+            p = perm.long()
+            sym, idx = sym.index_select(1, p), idx.index_select(1, p)
+        cdf, cdf_len, off = self.tables()
+        both = torch.stack([sym, idx]).cpu().numpy()
+        return [_rans_encode(both[0], both[1], cdf, cdf_len, off)]
+
+    def decompress_features(self, strings, params, c):
+        """params rows must be in the bitstream's row order.  -> y_hat [N, C]."""
+        n = params.shape[0]
+        dev = params.device
+        idx = self.indexes_for(params, c)
+        cdf, cdf_len, off = self.tables()
+        sym = torch.from_numpy(_rans_decode(strings[0], idx.cpu().numpy(), cdf, cdf_len, off).reshape(c, n)).to(dev)
+        yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
+        check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
+        return yhat
+
+    def forward_features(self, y_feats, params):
+        n, c = y_feats.shape
+        dev = y_feats.device
+        yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
+        lik = torch.empty((c, n), dtype=torch.float32, device=dev)
+        check(_lib.lib().pcc_gc_forward(ptr(y_feats.contiguous()), ptr(params.contiguous()), n, c, ptr(yhat), ptr(lik),
+                                        _lib.stream()))
+        return yhat, lik
+
+    # reference-shaped wrappers ((1, C, N) tensors) ------------------------------------------------
+    def build_indexes(self, scales):
+        c, n = scales.shape[1], scales.shape[2]
+        params = torch.cat([scales[0].t(), torch.zeros((n, c), device=scales.device)], dim=1).contiguous()
+        return self.indexes_for(params, c).unsqueeze(0)
+
+    def forward(self, inputs, scales, means=None, training=None):
+        if self.training if training is None else training:
+            raise NotImplementedError("training-mode (noise) quantisation is outside this round's scope (SURVEY §8f)")
+        means = torch.zeros_like(inputs) if means is None else means
+        params = torch.cat([scales[0].t(), means[0].t()], dim=1).contiguous()
+        yhat, lik = self.forward_features(inputs[0].t().contiguous(), params)
+        return yhat.t().unsqueeze(0), lik.unsqueeze(0)

@@ -1,0 +1,113 @@
+"""Mean-scale hyperprior on sparse tensors with the q-map decoded from z_hat.
+
+Mirror of ``MeanScaleHyperprior_Map`` (/root/reference/model/entropy_models.py:253-414): h_a, h_s,
+h_q, factorized bottleneck on z, Gaussian conditional on y, one rANS stream each.
+
+Differences in *how* (never in *what*):
+* the reference's ``Sorted*`` shims (entropy_models.py:12-102) exist to make h_s reproducible
+  between encoder and decoder; here every convolution output is a pure function of its own
+  neighbourhood with a fixed accumulation order (csrc/conv.hip), so plain layers are used for h_s
+  and no re-sorting is needed.  Parameter names are unchanged.
+* tensors are never physically sorted: the canonical (b,x,y,z) order (utils.sort_tensor,
+  utils.py:155-180) is applied as a column permutation of the symbol planes just before rANS.
+* h_s's last convolution is evaluated only at y's coordinates — the only rows the reference
+  reads (entropy_models.py:364,401) — which also makes (scales | means) row-aligned with y.
+"""
+import torch
+import torch.nn as nn
+
+from . import sparse as sp
+from .entropy import EntropyBottleneck, GaussianConditional, get_scale_table
+from .sparse import (ConvChain, CoordMap, MinkowskiConvolution, MinkowskiConvolutionTranspose,
+                     MinkowskiGenerativeConvolutionTranspose, MinkowskiLeakyReLU, MinkowskiReLU, SparseTensor)
+
+
+def _c(cin, cout, k=3, s=1, bias=False):
+    return MinkowskiConvolution(in_channels=cin, out_channels=cout, kernel_size=k, stride=s, bias=bias, dimension=3)
+
+
+class MeanScaleHyperprior_Map(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        Cb, Ch, Cq = config["C_bottleneck"], config["C_hyper_bottleneck"], config["C_Q"]
+        self.C_bottleneck = Cb
+        self.entropy_bottleneck = EntropyBottleneck(Ch)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.h_a = ConvChain(
+            _c(Cb, Ch), MinkowskiLeakyReLU(),
+            _c(Ch, Ch, 3, 2), _c(Ch, Ch), MinkowskiLeakyReLU(),
+            _c(Ch, Ch, 3, 2), _c(Ch, Ch))
+        gT = lambda cin, cout, k: MinkowskiGenerativeConvolutionTranspose(
+            in_channels=cin, out_channels=cout, kernel_size=k, stride=2, bias=True, dimension=3)
+        cT = lambda cin, cout, k: MinkowskiConvolutionTranspose(
+            in_channels=cin, out_channels=cout, kernel_size=k, stride=2, bias=True, dimension=3)
+        self.h_s = ConvChain(
+            _c(Ch, Ch, bias=True), gT(Ch, Ch, 2), MinkowskiLeakyReLU(),
+            _c(Ch, Ch, bias=True), gT(Ch, Cb * 3 // 2, 2), MinkowskiLeakyReLU(),
+            _c(Cb * 3 // 2, Cb * 2, bias=True))
+        self.h_q = ConvChain(
+            _c(Ch, Ch, bias=True), cT(Ch, Ch, 3), MinkowskiReLU(),
+            _c(Ch, Ch, bias=True), cT(Ch, Ch, 3), MinkowskiReLU(),
+            _c(Ch, Cq, bias=True))
+
+    # compressai CompressionModel surface ------------------------------------------------------------
+    def update(self, scale_table=None, force=False):
+        """model/model.py:30-36 -> CompressionModel.update(force=True): EB tables + the default
+        64-level Gaussian table."""
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        return updated
+
+    def aux_loss(self):
+        return self.entropy_bottleneck.loss()
+
+    # ------------------------------------------------------------------------------------------------
+    def _params_at(self, z_hat, y_map):
+        """h_s(z_hat) evaluated at y's coordinates -> [N_y, 2*C] = (scales | means)."""
+        return self.h_s(z_hat, last_out_map=y_map).F
+
+    def forward(self, y):
+        """Eval-mode forward (entropy_models.py:309-337): -> y_hat, Q_hat, (L_y, L_z)."""
+        z = self.h_a(y)
+        z_in = z.F.t().unsqueeze(0)
+        z_hat_f, z_lik = self.entropy_bottleneck(z_in)
+        z_hat = SparseTensor(z_hat_f[0].t().contiguous(), coordinate_map=z.map)
+        params = self._params_at(z_hat, y.map)
+        Q_hat = self.h_q(z_hat)
+        y_hat_f, y_lik = self.gaussian_conditional.forward_features(y.F, params)
+        y_hat = SparseTensor(y_hat_f, coordinate_map=y.map)
+        return y_hat, Q_hat, (y_lik.unsqueeze(0), z_lik)
+
+    def compress(self, y):
+        """entropy_models.py:341-381 -> (points, strings, shape)."""
+        z = self.h_a(y)
+        perm_y = y.map.sort_permutation()
+        perm_z = z.map.sort_permutation()
+        shape = [z.map.n]
+        z_strings, z_hat_f = self.entropy_bottleneck.compress_features(z.F, perm=perm_z)
+        z_hat = SparseTensor(z_hat_f, coordinate_map=z.map)
+        params = self._params_at(z_hat, y.map)
+        y_strings = self.gaussian_conditional.compress_features(y.F, params, perm=perm_y)
+        points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
+        return points, [y_strings, z_strings], shape
+
+    def decompress(self, points, strings, shape):
+        """entropy_models.py:384-414 -> (y_hat, Q_hat); ``points`` = [coords8, coords32] or CoordMaps."""
+        assert isinstance(strings, list) and len(strings) == 2
+        y_map, z_map = points
+        if not isinstance(y_map, CoordMap):
+            y_map = CoordMap(sp._as_int_coords(y_map), 8)
+        if not isinstance(z_map, CoordMap):
+            z_map = CoordMap(sp._as_int_coords(z_map), 32)
+        # canonical order = bitstream order (utils.sort_points)
+        y_sorted = CoordMap(y_map.coords.index_select(0, y_map.sort_permutation().long()), 8, nbatch=y_map._nbatch)
+        z_sorted = CoordMap(z_map.coords.index_select(0, z_map.sort_permutation().long()), 32, nbatch=z_map._nbatch)
+        y_strings, z_strings = strings
+        z_hat_f = self.entropy_bottleneck.decompress_features(z_strings, int(shape[0]), z_sorted.device)
+        z_hat = SparseTensor(z_hat_f, coordinate_map=z_sorted)
+        Q_hat = self.h_q(z_hat)
+        params = self._params_at(z_hat, y_sorted)
+        y_hat_f = self.gaussian_conditional.decompress_features(y_strings, params, self.C_bottleneck)
+        return SparseTensor(y_hat_f, coordinate_map=y_sorted), Q_hat

@@ -1,0 +1,128 @@
+"""ColorModel — the codec facade (drop-in for /root/reference/model/model.py:15-208).
+
+Same constructor config, same ``forward`` / ``compress`` / ``decompress`` / ``update`` /
+``aux_loss`` signatures and return values as the reference, running on libpcc_hip.so.
+
+File mode (``path=...``): the reference shells out to the MPEG G-PCC ``tmc3`` binary for the
+stride-8 latent coordinates (model/model.py:318-395); that binary is not part of this path
+(SURVEY.md N15, §8f rank 2).  The 28-byte header and payload order of the container are kept
+(model/model.py:241-256); the coordinate payload is written by a small lossless placeholder
+coder (sorted int16 deltas + zlib) and is NOT G-PCC-compatible.
+"""
+import struct
+import zlib
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import sparse as sp
+from .entropy_models import MeanScaleHyperprior_Map
+from .sparse import CoordMap, SparseTensor
+from .transforms import AnalysisTransform, SparseSynthesisTransform
+
+
+class ColorModel(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.g_a = AnalysisTransform(config["g_a"])
+        self.g_s = SparseSynthesisTransform(config["g_s"])
+        if "entropy_model_map" in config:
+            raise NotImplementedError("the two-hyperprior variant (model/model.py:22-24) is not used by any "
+                                      "shipped config and is outside this path")
+        self.entropy_model = MeanScaleHyperprior_Map(config["entropy_model"])
+        self.entropy_model_map = None
+
+    # -- model/model.py:30-47 ------------------------------------------------------------------
+    def update(self, force=True):
+        return self.entropy_model.update(force=force)
+
+    def aux_loss(self):
+        return self.entropy_model.aux_loss()
+
+    @property
+    def device(self):
+        return self.g_s.down_conv.kernel.device
+
+    # -- model/model.py:51-93 (eval mode) -----------------------------------------------------------
+    def forward(self, x, Q, Lambda=None):
+        if self.training:
+            raise NotImplementedError("training forward/backward is the next scope row (SURVEY.md §8f); "
+                                      "call .eval() for the inference forward")
+        coords = SparseTensor(coordinate_map=x.map)
+        ones = torch.ones((x.map.n, 1), dtype=torch.float32, device=x.device)
+        x = SparseTensor(torch.cat([ones, x.F], dim=1), coordinate_map=x.map)
+        y, Q, k = self.g_a(x, Q)
+        y_hat, Q_hat, likelihoods = self.entropy_model(y)
+        likelihoods = {"y": likelihoods[0], "z": likelihoods[1]}
+        x_hat, points, predictions = self.g_s(y_hat, Q_hat, coords=coords, k=k)
+        return {"prediction": x_hat, "points": points, "occ_predictions": predictions, "q_map": Lambda,
+                "likelihoods": likelihoods}
+
+    # -- model/model.py:95-147 -------------------------------------------------------------------------
+    @torch.no_grad()
+    def compress(self, x, Q, path=None):
+        N = x.shape[0]
+        dev = x.device
+        coords = torch.cat([torch.zeros((N, 1), device=dev, dtype=torch.int32), x[:, :3].to(torch.int32)], dim=1)
+        feats = torch.cat([torch.ones((N, 1), device=dev, dtype=torch.float32), x[:, 3:6].float()], dim=1)
+        inp = SparseTensor(feats, coordinate_map=CoordMap(coords.contiguous(), 1, nbatch=1))
+        if Q.map._nbatch is None:
+            Q.map._nbatch = 1
+        y, _, k = self.g_a(inp, Q)
+        points, strings, shape = self.entropy_model.compress(y)
+        coordinates = y.C
+        if path:
+            self.save_bitstream(path=path, points=coordinates, strings=strings, shape=shape, k=k)
+            return None
+        return strings, shape, k, coordinates
+
+    # -- model/model.py:152-208 ------------------------------------------------------------------------
+    @torch.no_grad()
+    def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None):
+        device = self.device
+        if path:
+            coordinates, strings, shape, k = self.load_bitstream(path)
+            coordinates = coordinates.to(device)
+            batch = torch.zeros((coordinates.shape[0], 1), device=device, dtype=coordinates.dtype)
+            coordinates = torch.cat([batch, coordinates], dim=1)
+        c8 = CoordMap(sp._as_int_coords(coordinates.to(device)), 8, nbatch=1)
+        c32 = c8.down().down()      # coordinates only (g_s.down_conv applied twice, model.py:188-190)
+        y_hat, Q_hat = self.entropy_model.decompress([c8, c32], strings, shape)
+        x_hat = self.g_s(y_hat, Q_hat, k=k)
+        feats = torch.clamp(torch.round(x_hat.F * 255), 0.0, 255.0) / 255
+        return torch.cat([x_hat.C[:, 1:4].to(feats.dtype), feats], dim=1)
+
+    # -- container (model/model.py:214-315) --------------------------------------------------------------
+    @staticmethod
+    def _encode_points(points):
+        """Placeholder lossless coder for the stride-8 coordinate list (NOT G-PCC)."""
+        p = points.detach().cpu().numpy()[:, 1:4].astype(np.int64)
+        order = np.lexsort((p[:, 2], p[:, 1], p[:, 0]))
+        p = p[order]
+        d = np.diff(p, axis=0, prepend=np.zeros((1, 3), dtype=np.int64)).astype("<i2")
+        return struct.pack("<I", p.shape[0]) + zlib.compress(d.tobytes(), 9)
+
+    @staticmethod
+    def _decode_points(data):
+        n = struct.unpack("<I", data[:4])[0]
+        d = np.frombuffer(zlib.decompress(data[4:]), dtype="<i2").reshape(n, 3).astype(np.int64)
+        return torch.from_numpy(np.cumsum(d, axis=0).astype(np.float64))
+
+    def save_bitstream(self, path, points, strings, shape, k):
+        pts = self._encode_points(points)
+        ks = [int(kk[0]) if isinstance(kk, (list, tuple)) else int(kk) for kk in k]
+        # 7 x int32, MSB first like the `bitstream` package: 28 bytes
+        header = struct.pack(">7i", int(shape[0]), len(pts), len(strings[0][0]), len(strings[1][0]), *ks)
+        with open(path, "wb") as f:
+            f.write(header + pts + strings[0][0] + strings[1][0])
+
+    def load_bitstream(self, path):
+        with open(path, "rb") as f:
+            data = f.read()
+        nz, lp, ly, lz, k0, k1, k2 = struct.unpack(">7I", data[:28])
+        o = 28
+        pts = data[o:o + lp]; o += lp
+        ys = data[o:o + ly]; o += ly
+        zs = data[o:o + lz]
+        return self._decode_points(pts), [[ys], [zs]], [int(nz)], [[int(k0)], [int(k1)], [int(k2)]]

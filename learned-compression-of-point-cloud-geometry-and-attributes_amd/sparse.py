@@ -1,0 +1,406 @@
+"""Sparse tensors and sparse-convolution layers on top of libpcc_hip.so.
+
+Host-side mirror of the MinkowskiEngine surface the reference uses:
+``SparseTensor`` (``.C``, ``.F``, ``.tensor_stride``, ``.device``, ``.coordinate_manager``,
+``.features_at_coordinates``), ``MinkowskiConvolution``, ``MinkowskiGenerativeConvolutionTranspose``,
+``MinkowskiConvolutionTranspose``, ``MinkowskiPruning``, ``MinkowskiReLU`` / ``MinkowskiLeakyReLU``.
+Layer parameters keep ME's names and shapes (``kernel`` [K, C_in, C_out] or [C_in, C_out] for
+kernel_size 1, ``bias`` [1, C_out]) so reference state_dicts load unchanged.
+
+Everything numeric runs in the HIP library; torch provides device memory, streams and the
+parameter containers only.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import check, ptr
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+
+def _require_cuda(t):
+    if not t.is_cuda:
+        raise RuntimeError("libpcc_hip operators need tensors on an MI355X device (got a CPU tensor); "
+                           "there is no CPU fallback")
+
+
+def _as_int_coords(coords):
+    """ME floors non-int32 coordinates (reference: model/model.py:184-188, utils.py:438)."""
+    if coords.dtype.is_floating_point:
+        coords = torch.floor(coords)
+    return coords.to(torch.int32).contiguous()
+
+
+class CoordMap:
+    """A coordinate set of one tensor stride with its hashed-voxel table and cached kernel maps.
+
+    Plays the role of ME's coordinate manager + coordinate-map key (N1-N3 of SURVEY.md §2.2).
+    """
+
+    def __init__(self, coords, stride=1, table=None, nbatch=None):
+        _require_cuda(coords)
+        assert coords.dtype == torch.int32 and coords.dim() == 2 and coords.shape[1] == 4
+        self.coords = coords.contiguous()
+        self.stride = int(stride)
+        self._table = table          # (keys uint64-as-int64, vals int32, cap)
+        self._nbatch = nbatch
+        self._cache = {}
+
+    # -- basic properties ------------------------------------------------------------------
+    @property
+    def n(self):
+        return self.coords.shape[0]
+
+    @property
+    def device(self):
+        return self.coords.device
+
+    @property
+    def nbatch(self):
+        if self._nbatch is None:
+            self._nbatch = int(self.coords[:, 0].max().item()) + 1 if self.n else 1
+        return self._nbatch
+
+    def table(self):
+        if self._table is None:
+            L = _lib.lib()
+            cap = L.pcc_hash_capacity(self.n)
+            keys = torch.empty(cap, dtype=torch.int64, device=self.device)
+            vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+            check(L.pcc_hash_build(ptr(self.coords), self.n, ptr(keys), ptr(vals), cap, None, _lib.stream()))
+            self._table = (keys, vals, cap)
+        return self._table
+
+    def lookup(self, query):
+        """Row index of every query coordinate (int32 [M,4]) or -1."""
+        keys, vals, cap = self.table()
+        q = _as_int_coords(query)
+        out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
+        check(_lib.lib().pcc_hash_lookup(ptr(keys), ptr(vals), cap, ptr(q), q.shape[0], ptr(out), _lib.stream()))
+        return out
+
+    # -- derived coordinate sets -------------------------------------------------------------
+    def _unique(self, fn_name, m, *args):
+        L = _lib.lib()
+        cap = L.pcc_hash_capacity(m)
+        dev = self.device
+        keys = torch.empty(cap, dtype=torch.int64, device=dev)
+        vals = torch.empty(cap, dtype=torch.int32, device=dev)
+        scratch = torch.empty(L.pcc_scan_scratch_elems(m), dtype=torch.int32, device=dev)
+        out = torch.empty((max(m, 1), 4), dtype=torch.int32, device=dev)
+        count = torch.empty(1, dtype=torch.int64, device=dev)
+        check(getattr(L, fn_name)(ptr(self.coords), self.n, *args, ptr(keys), ptr(vals), cap, ptr(scratch),
+                                  ptr(out), ptr(count), _lib.stream()))
+        n_out = int(count.item())      # the one host sync of a coordinate-set construction
+        return out[:n_out], (keys, vals, cap)
+
+    def down(self):
+        """Coordinate set of a stride-2 convolution output (ME stride map)."""
+        if "down" not in self._cache:
+            coords, table = self._unique("pcc_stride_map", self.n, self.stride)
+            self._cache["down"] = CoordMap(coords, self.stride * 2, table, self._nbatch)
+        return self._cache["down"]
+
+    def up(self, ksize):
+        """Coordinate set of a generative transposed convolution output (kernel 2 or 3, stride 2)."""
+        key = ("up", ksize)
+        if key not in self._cache:
+            coords, table = self._unique("pcc_children", self.n * ksize ** 3, self.stride, ksize)
+            self._cache[key] = CoordMap(coords, self.stride // 2, table, self._nbatch)
+        return self._cache[key]
+
+    def kernel_map(self, out_map, ksize, transposed=False):
+        """(nbr int32 [N_out, K], group_mask) for input=self, output=out_map."""
+        key = ("kmap", id(out_map), ksize, transposed)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] is out_map:
+            return hit[1], hit[2]
+        keys, vals, cap = self.table()
+        K = ksize ** 3
+        n_out = out_map.n
+        nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.device)
+        gmask = torch.empty((n_out + 63) // 64, dtype=torch.int32, device=self.device)
+        step = self.stride // 2 if transposed else self.stride
+        check(_lib.lib().pcc_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step,
+                                        -1 if transposed else 1, ptr(nbr), ptr(gmask), _lib.stream()))
+        self._cache[key] = (out_map, nbr, gmask)   # keeps out_map alive so id() stays unique
+        return nbr, gmask
+
+    def count_per_batch(self):
+        """AnalysisTransform.count_per_batch (model/transforms.py:65-71)."""
+        if self._nbatch == 1:
+            return [self.n]
+        nb = self.nbatch
+        counts = torch.empty(nb, dtype=torch.int32, device=self.device)
+        check(_lib.lib().pcc_count_per_batch(ptr(self.coords), self.n, nb, ptr(counts), _lib.stream()))
+        return [int(v) for v in counts.tolist() if v > 0]
+
+    def sort_permutation(self):
+        """perm with coords[perm] in canonical (b,x,y,z) order (utils.py:155-204)."""
+        L = _lib.lib()
+        nbytes = L.pcc_sort_scratch_bytes(self.n)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        perm = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        check(L.pcc_sort_coords(ptr(self.coords), self.n, ptr(perm), ptr(scratch), nbytes, _lib.stream()))
+        return perm
+
+
+class SparseTensor:
+    """Features [N, C] on a CoordMap.  Mirrors the ME.SparseTensor surface used by the reference."""
+
+    def __init__(self, features=None, coordinates=None, tensor_stride=1, coordinate_manager=None,
+                 device=None, coordinate_map=None, nbatch=None):
+        if coordinate_map is None:
+            if coordinates is None:
+                raise ValueError("coordinates or coordinate_map required")
+            if device is not None:
+                coordinates = coordinates.to(device)
+            if isinstance(tensor_stride, (list, tuple)):
+                tensor_stride = tensor_stride[0]
+            coordinate_map = CoordMap(_as_int_coords(coordinates), tensor_stride, nbatch=nbatch)
+        self.map = coordinate_map
+        if features is None:
+            features = torch.ones((self.map.n, 1), dtype=torch.float32, device=self.map.device)
+        features = features.to(device=self.map.device, dtype=torch.float32)
+        if features.shape[0] != self.map.n:
+            raise ValueError(f"{features.shape[0]} feature rows for {self.map.n} coordinates")
+        self.F = features.contiguous()
+
+    @property
+    def C(self):
+        return self.map.coords
+
+    @property
+    def tensor_stride(self):
+        return [self.map.stride] * 3
+
+    @property
+    def coordinate_manager(self):
+        return self.map
+
+    @property
+    def device(self):
+        return self.F.device
+
+    @property
+    def shape(self):
+        return self.F.shape
+
+    def features_at_coordinates(self, query):
+        """Exact lookup, zero-fill if absent (every query on the path is on-grid: SURVEY.md N8)."""
+        idx = self.map.lookup(query)
+        return gather_rows(self.F, idx)
+
+
+# ---------------------------------------------------------------------------------------------
+# functional operators
+# ---------------------------------------------------------------------------------------------
+def gather_rows(src, idx, out=None, accumulate=False):
+    n = idx.shape[0]
+    c = src.shape[1]
+    if out is None:
+        out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    check(_lib.lib().pcc_gather_rows(ptr(src), c, ptr(idx), n, ptr(out), 1 if accumulate else 0, _lib.stream()))
+    return out
+
+
+def scatter_rows(src, idx, n_out):
+    out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
+    check(_lib.lib().pcc_scatter_rows(ptr(src), src.shape[1], ptr(idx), idx.shape[0], ptr(out), _lib.stream()))
+    return out
+
+
+def compact_rows(mask, coords=None, feats=None, want_index=False):
+    """Order-preserving compaction (ME.MinkowskiPruning).  Returns (coords, feats, new_index, n)."""
+    L = _lib.lib()
+    n = mask.shape[0]
+    dev = mask.device
+    scratch = torch.empty(L.pcc_scan_scratch_elems(n), dtype=torch.int32, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    out_c = torch.empty((n, 4), dtype=torch.int32, device=dev) if coords is not None else None
+    c = feats.shape[1] if feats is not None else 0
+    out_f = torch.empty((n, c), dtype=torch.float32, device=dev) if feats is not None else None
+    new_index = torch.empty(n, dtype=torch.int32, device=dev) if want_index else None
+    check(L.pcc_compact_rows(ptr(mask), n, ptr(coords), ptr(out_c), ptr(feats), c, ptr(out_f), ptr(new_index),
+                             ptr(scratch), ptr(count), _lib.stream()))
+    m = int(count.item())
+    return (out_c[:m] if out_c is not None else None, out_f[:m] if out_f is not None else None, new_index, m)
+
+
+def topk_mask(logits, coords, k_per_batch, nbatch):
+    """Per-batch top-k on column 0 of ``logits`` (model/blocks.py:130-150)."""
+    L = _lib.lib()
+    n = logits.shape[0]
+    dev = logits.device
+    k = torch.tensor([int(v) for v in k_per_batch], dtype=torch.int32, device=dev)
+    assert k.numel() == nbatch, (k.numel(), nbatch)
+    state = torch.empty(L.pcc_topk_state_elems(nbatch), dtype=torch.int32, device=dev)
+    mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    check(L.pcc_topk_mask(ptr(logits), logits.stride(0), ptr(coords), n, nbatch, ptr(k), ptr(mask), ptr(state),
+                          _lib.stream()))
+    return mask
+
+
+def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=ACT_NONE, film=None,
+                 residual=None, out_channels=None):
+    """out = act(film(bias + sum_k in[nbr] @ W[k])) + residual — one fused launch."""
+    L = _lib.lib()
+    w, wp, bias = layer.weights(out_channels)
+    cin = x_feats.shape[1]
+    cout = w.shape[-1]
+    if ksize == 1:
+        nbr = gmask = None
+        K = 1
+    else:
+        nbr, gmask = in_map.kernel_map(out_map, ksize, transposed)
+        K = ksize ** 3
+    n_out = out_map.n
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
+    check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(gmask), K,
+                         ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# layers (parameter containers + forward through the fused operator)
+# ---------------------------------------------------------------------------------------------
+class _ConvBase(nn.Module):
+    transposed = False
+    generative = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False, dimension=3):
+        super().__init__()
+        assert dimension == 3 and dilation == 1
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = int(kernel_size), int(stride)
+        K = self.kernel_size ** 3
+        shape = (in_channels, out_channels) if K == 1 else (K, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(shape, dtype=torch.float32))
+        self.bias = nn.Parameter(torch.empty((1, out_channels), dtype=torch.float32)) if bias else None
+        self.reset_parameters()
+        self._packed = {}
+
+    def reset_parameters(self):
+        """ME default: U(-1/sqrt(n), 1/sqrt(n)), n = C_in*K (C_out*K when transposed)."""
+        K = self.kernel_size ** 3
+        n = (self.out_channels if self.transposed else self.in_channels) * K
+        bound = 1.0 / math.sqrt(n)
+        with torch.no_grad():
+            self.kernel.uniform_(-bound, bound)
+            if self.bias is not None:
+                self.bias.uniform_(-bound, bound)
+
+    def weights(self, out_channels=None):
+        """(raw kernel, MFMA-packed kernel or None, bias or None), optionally sliced to the first
+        ``out_channels`` outputs (used where the reference reads only channel 0: blocks.py:142)."""
+        key = (self.kernel._version, self.kernel.data_ptr(), out_channels,
+               None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        hit = self._packed.get("w")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w = self.kernel.detach()
+        _require_cuda(w)
+        if w.dim() == 2:
+            w = w.unsqueeze(0)
+        b = None if self.bias is None else self.bias.detach().reshape(-1)
+        if out_channels is not None:
+            w = w[:, :, :out_channels]
+            b = None if b is None else b[:out_channels]
+        w = w.contiguous()
+        b = None if b is None else b.contiguous()
+        K, cin, cout = w.shape
+        wp = None
+        if cin % 32 == 0:
+            L = _lib.lib()
+            wp = torch.empty(L.pcc_conv_packed_elems(K, cin, cout), dtype=torch.float32, device=w.device)
+            check(L.pcc_conv_pack_weights(ptr(w), K, cin, cout, ptr(wp), _lib.stream()))
+        res = (w, wp, b)
+        self._packed["w"] = (key, res)
+        return res
+
+    def output_map(self, in_map):
+        if self.transposed:
+            assert self.stride == 2
+            return in_map.up(self.kernel_size)
+        if self.stride == 1:
+            return in_map
+        assert self.stride == 2
+        return in_map.down()
+
+    def forward(self, x, act=ACT_NONE, film=None, residual=None, out_map=None, out_channels=None):
+        if out_map is None:
+            out_map = self.output_map(x.map)
+        feats = conv_forward(x.F, x.map, out_map, self, self.kernel_size, self.transposed, act, film, residual,
+                             out_channels)
+        return SparseTensor(feats, coordinate_map=out_map)
+
+
+class MinkowskiConvolution(_ConvBase):
+    """ME.MinkowskiConvolution (model/transforms.py:35-57 etc.)."""
+
+
+class MinkowskiGenerativeConvolutionTranspose(_ConvBase):
+    """ME.MinkowskiGenerativeConvolutionTranspose (model/blocks.py:84, entropy_models.py:286,290)."""
+    transposed = True
+    generative = True
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    """ME.MinkowskiConvolutionTranspose (model/entropy_models.py:298,302).  Output coordinates are
+    generated like the generative variant (decode semantics)."""
+    transposed = True
+
+
+class MinkowskiReLU(nn.Module):
+    """Placeholder keeping the reference's nn.Sequential indices; the activation itself is fused
+    into the preceding convolution's epilogue."""
+    act = ACT_RELU
+
+    def __init__(self, inplace=False):
+        super().__init__()
+
+
+class MinkowskiLeakyReLU(MinkowskiReLU):
+    act = ACT_LRELU
+
+
+class ConvChain(nn.Sequential):
+    """nn.Sequential of conv / activation modules executed with fused activations.
+
+    Module indices (hence state_dict keys such as ``conv_1.0.kernel``) match the reference's
+    nn.Sequential definitions.
+    """
+
+    def plan(self):
+        steps = []
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            assert isinstance(m, _ConvBase), f"unexpected module {type(m)} at {i}"
+            act = ACT_NONE
+            if i + 1 < len(mods) and isinstance(mods[i + 1], MinkowskiReLU):
+                act = mods[i + 1].act
+                i += 1
+            steps.append((m, act))
+            i += 1
+        return steps
+
+    def forward(self, x, last_film=None, last_residual=None, last_out_map=None, last_out_channels=None):
+        steps = self.plan()
+        for j, (m, act) in enumerate(steps):
+            last = j == len(steps) - 1
+            x = m(x, act=act, film=last_film if last else None, residual=last_residual if last else None,
+                  out_map=last_out_map if last else None, out_channels=last_out_channels if last else None)
+        return x
+
+
+class MinkowskiPruning(nn.Module):
+    """ME.MinkowskiPruning (model/blocks.py:90,126)."""
+
+    def forward(self, x, mask):
+        coords, feats, _, _ = compact_rows(mask.to(torch.uint8), x.C, x.F)
+        return SparseTensor(feats, coordinate_map=CoordMap(coords, x.map.stride, nbatch=x.map._nbatch))

@@ -1,0 +1,22 @@
+"""CPU oracle for the joint geometry+attribute point-cloud codec hot path.
+
+TEST INFRASTRUCTURE ONLY.  This package is a CPU restatement (numpy integer
+arithmetic + torch-CPU fp32 matmuls + a small C rANS coder) of the algorithm in
+the reference's ``model/{model,transforms,blocks,entropy_models}.py`` and of the
+third-party operator semantics it relies on (MinkowskiEngine 0.5.4 — version
+unpinned upstream — and compressai 1.2.4, neither present under /root/reference
+nor installable here).  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it, and only as the checker.
+The product package never imports it and fails loudly without its HIP library.
+
+PARITY PINNING STATUS: "parity unpinned" at the third-party operator boundary.
+The reference ships no tests, golden vectors or fixtures for this path
+(SURVEY.md §4, §8c), MinkowskiEngine / compressai cannot be imported
+(ModuleNotFoundError), and no trained weights exist.  The oracle is pinned
+instead by (i) hand-derivable integer known-answer tests, (ii) the structural
+facts the reference itself fixes (parameter count 31,469,942 <-> README.md:125,
+28-byte header model/model.py:243-250, k order transforms.py:89-127, q-map
+channel order utils.py:439), (iii) C / pure-Python rANS twins that must agree
+byte for byte, and (iv) committed golden vectors under tests/golden/ generated
+by tests/golden/make_golden.py.
+"""

@@ -1,0 +1,68 @@
+"""Oracle: D1 (point-to-point) PSNR and Y/U/V PSNR, CPU (numpy + scipy cKDTree).
+
+Restates /root/reference/metrics/metric.py:61-189 (``PointCloudMetric`` with
+``drop_duplicates=True`` as called at train.py:263-264): nearest-neighbour
+association in both directions, geometry MSE = mean over points of the mean
+squared coordinate difference (metric.py:113-119), colours rounded to 8 bit and
+converted with the BT.709 matrix after a truncating uint8 cast
+(metric.py:149-150,171-189), symmetric value = min over the two directions
+(metric.py:72-83).  open3d's KD-tree is replaced by scipy's; ties between
+equidistant neighbours may resolve differently (unpinned).
+Test infrastructure only — see oracle/__init__.py.
+"""
+import numpy as np
+from scipy.spatial import cKDTree
+
+
+def rgb_to_yuv(rgb):
+    rgb = np.asarray(rgb, dtype=np.float64)
+    scale = rgb.max() <= 1.0
+    if scale:
+        rgb = (rgb * 255).astype(np.uint8)
+    yuv = np.empty(rgb.shape, dtype=np.float32)
+    yuv[..., 0] = 0.2126 * rgb[..., 0] + 0.7152 * rgb[..., 1] + 0.0722 * rgb[..., 2]
+    yuv[..., 1] = -0.1146 * rgb[..., 0] - 0.3854 * rgb[..., 1] + 0.5 * rgb[..., 2]
+    yuv[..., 2] = 0.5 * rgb[..., 0] - 0.4542 * rgb[..., 1] - 0.0458 * rgb[..., 2]
+    if scale:
+        yuv = yuv / 255.0
+        yuv[..., 1] += 0.5
+        yuv[..., 2] += 0.5
+    return yuv
+
+
+def _dedupe(pc):
+    pts = pc[:, :3]
+    _, first = np.unique(pts, axis=0, return_index=True)
+    return pc[np.sort(first)]
+
+
+def _one_way(a, b, resolution):
+    tree = cKDTree(b[:, :3])
+    _, nn = tree.query(a[:, :3], k=1)
+    d = ((a[:, :3] - b[nn, :3]) ** 2).mean(axis=1)
+    res = {"mse": d.mean(), "hausdorff": d.max()}
+    res["psnr_mse"] = 10 * np.log10(resolution ** 2 / res["mse"]) if res["mse"] > 0 else np.inf
+    a_yuv = rgb_to_yuv(np.clip(np.round(a[:, 3:6] * 255.0) / 255.0, 0.0, 1.0))
+    b_yuv = rgb_to_yuv(np.clip(np.round(b[nn, 3:6] * 255.0) / 255.0, 0.0, 1.0))
+    e = ((a_yuv - b_yuv) ** 2).mean(axis=0)
+    for i, ch in enumerate("yuv"):
+        res[f"{ch}_mse"] = e[i]
+        res[f"{ch}_psnr"] = 10 * np.log10(1 / e[i]) if e[i] > 0 else np.inf
+    return res
+
+
+def pc_metrics(source, recon, resolution=1023):
+    """source/recon: float [N,6] (xyz voxel coords, rgb in [0,1])."""
+    a = _dedupe(np.asarray(source, dtype=np.float64))
+    b = _dedupe(np.asarray(recon, dtype=np.float64))
+    ab = _one_way(a, b, resolution)
+    ba = _one_way(b, a, resolution)
+    out = {}
+    for kk in ab:
+        out["AB_" + kk] = ab[kk]
+        out["BA_" + kk] = ba[kk]
+    out["sym_psnr_mse"] = min(ab["psnr_mse"], ba["psnr_mse"])
+    out["sym_y_psnr"] = min(ab["y_psnr"], ba["y_psnr"])
+    out["sym_u_psnr"] = min(ab["u_psnr"], ba["u_psnr"])
+    out["sym_v_psnr"] = min(ab["v_psnr"], ba["v_psnr"])
+    return out

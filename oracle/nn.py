@@ -1,0 +1,140 @@
+"""Oracle: sparse tensor + sparse convolution arithmetic (torch-CPU fp32).
+
+Restates the MinkowskiEngine operators used on the path (SURVEY.md §2.2 N3-N9,
+Appendix B.1): ``out[j] = bias + sum_k in[nbr(j,k)] @ W[k]`` with the kernel
+tensor ``[K, C_in, C_out]`` (``[C_in, C_out]`` for kernel_size 1) and bias
+``[1, C_out]``, accumulated per kernel offset in fixed order k = 0..K-1
+(gather -> sgemm -> index_add_).
+
+Test infrastructure only — see oracle/__init__.py.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+from . import coords as oc
+
+
+@dataclass
+class SparseTensor:
+    """Minimal stand-in for ME.SparseTensor: ``C`` int32 [N,4], ``F`` fp32 [N,C]."""
+    C: np.ndarray
+    F: torch.Tensor
+    stride: int = 1
+    _cache: dict = field(default_factory=dict, repr=False)
+
+    def __post_init__(self):
+        self.C = oc.to_int_coords(self.C)
+        self.F = torch.as_tensor(self.F, dtype=torch.float32)
+        assert self.C.shape[0] == self.F.shape[0]
+
+    def features_at_coordinates(self, query):
+        """On-grid lookup, zero-fill when absent (blocks.py:37,50)."""
+        q = oc.to_int_coords(query)
+        idx = oc.lookup(self.C, q)
+        out = torch.zeros((q.shape[0], self.F.shape[1]), dtype=torch.float32)
+        hit = idx >= 0
+        out[torch.from_numpy(hit)] = self.F[torch.from_numpy(idx[hit])]
+        return out
+
+    def sorted(self):
+        """utils.sort_tensor (utils.py:155-180)."""
+        order = oc.sort_order(self.C)
+        return SparseTensor(self.C[order], self.F[torch.from_numpy(order)], self.stride)
+
+
+def _apply_conv(F_in, W, bias, nbr, n_out):
+    K = nbr.shape[1]
+    if W.dim() == 2:
+        W = W[None]
+    assert W.shape[0] == K, (W.shape, K)
+    out = torch.zeros((n_out, W.shape[2]), dtype=torch.float32)
+    for k in range(K):
+        col = nbr[:, k]
+        rows = np.nonzero(col >= 0)[0]
+        if rows.size == 0:
+            continue
+        src = torch.from_numpy(col[rows])
+        out.index_add_(0, torch.from_numpy(rows), F_in[src] @ W[k])
+    if bias is not None:
+        out += bias.reshape(1, -1)
+    return out
+
+
+def conv(x, W, bias=None, ksize=3, stride=1):
+    """ME.MinkowskiConvolution (transforms.py:35-57 etc.)."""
+    if ksize == 1:
+        assert stride == 1
+        Wk = W if W.dim() == 2 else W[0]
+        out = x.F @ Wk
+        if bias is not None:
+            out = out + bias.reshape(1, -1)
+        return SparseTensor(x.C, out, x.stride)
+    if stride == 1:
+        key = ("nbr", ksize, 1)
+        if key not in x._cache:
+            x._cache[key] = oc.kernel_map(x.C, x.C, ksize, x.stride)
+        nbr = x._cache[key]
+        y = SparseTensor(x.C, _apply_conv(x.F, W, bias, nbr, x.C.shape[0]), x.stride)
+        y._cache = x._cache  # same coordinate map -> share kernel maps (ME caches them too)
+        return y
+    assert stride == 2
+    key = ("down", ksize)
+    if key not in x._cache:
+        out_c = oc.stride_map(x.C, x.stride)
+        x._cache[key] = (out_c, oc.kernel_map(x.C, out_c, ksize, x.stride))
+    out_c, nbr = x._cache[key]
+    return SparseTensor(out_c, _apply_conv(x.F, W, bias, nbr, out_c.shape[0]), x.stride * 2)
+
+
+def conv_transpose_generative(x, W, bias=None, ksize=3):
+    """ME.MinkowskiGenerativeConvolutionTranspose, stride 2 (blocks.py:84;
+    entropy_models.py:286,290) — also the non-generative ConvTranspose of h_q on a
+    fresh coordinate manager (entropy_models.py:298,302)."""
+    key = ("up", ksize)
+    if key not in x._cache:
+        out_c = oc.children(x.C, x.stride, ksize)
+        x._cache[key] = (out_c, oc.kernel_map(x.C, out_c, ksize, x.stride // 2, transposed=True))
+    out_c, nbr = x._cache[key]
+    return SparseTensor(out_c, _apply_conv(x.F, W, bias, nbr, out_c.shape[0]), x.stride // 2)
+
+
+def relu(x):
+    y = SparseTensor(x.C, torch.relu(x.F), x.stride)
+    y._cache = x._cache
+    return y
+
+
+def leaky_relu(x, slope=0.01):
+    y = SparseTensor(x.C, torch.nn.functional.leaky_relu(x.F, slope), x.stride)
+    y._cache = x._cache
+    return y
+
+
+def prune(x, mask):
+    """ME.MinkowskiPruning: order-preserving row compaction (blocks.py:90,126)."""
+    m = np.asarray(mask, dtype=bool)
+    return SparseTensor(x.C[m], x.F[torch.from_numpy(m)], x.stride)
+
+
+class Params:
+    """View on a flat state_dict with a dotted prefix."""
+
+    def __init__(self, sd, prefix=""):
+        self.sd, self.prefix = sd, prefix
+
+    def sub(self, name):
+        return Params(self.sd, f"{self.prefix}{name}.")
+
+    def get(self, name, default=None):
+        v = self.sd.get(self.prefix + name, default)
+        return None if v is None else torch.as_tensor(v, dtype=torch.float32)
+
+    def conv(self, x, name, ksize=3, stride=1):
+        p = self.sub(name)
+        return conv(x, p.get("kernel"), p.get("bias"), ksize, stride)
+
+    def convT(self, x, name, ksize=3):
+        p = self.sub(name)
+        return conv_transpose_generative(x, p.get("kernel"), p.get("bias"), ksize)
