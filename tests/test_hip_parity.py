@@ -1,0 +1,341 @@
+"""GPU parity tests: every libpcc_hip.so operator against the CPU oracle on the same seeded inputs.
+
+Bit-exact for integer / index / byte work; fp32 convolution within the tolerance written in
+each test (the HIP kernels and MKL sgemm sum in different orders).  Run on the MI355X box with
+``pytest -m gpu``.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import nn as on
+from oracle import entropy as oe
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def shell_coords(pcc, grid=48, radius=20.0, hw=0.9, batch=1, seed=0):
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(batch):
+        p = pcc.synthetic.sphere_shell(grid, radius - 2 * b, hw)[:, :3]
+        c = np.concatenate([np.full((p.shape[0], 1), b), p], axis=1).astype(np.int32)
+        out.append(c)
+    c = np.concatenate(out, axis=0)
+    return c[rng.permutation(c.shape[0])]
+
+
+def as_set(c):
+    return set(map(tuple, np.asarray(c).tolist()))
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(a)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+def test_library_reports_gfx950(pcc):
+    L = pcc.lib()
+    assert L.pcc_device_count() >= 1
+    import ctypes
+    buf = ctypes.create_string_buffer(256)
+    assert L.pcc_device_name(0, buf, 256) == 0
+    assert b"gfx950" in buf.value, buf.value
+
+
+def test_hash_lookup(pcc):
+    c = shell_coords(pcc, batch=2)
+    m = pcc.CoordMap(dev(c), 1)
+    rng = np.random.default_rng(3)
+    q = np.concatenate([c[rng.integers(0, c.shape[0], 2000)],
+                        np.concatenate([rng.integers(0, 2, (2000, 1)), rng.integers(-5, 55, (2000, 3))], axis=1)]).astype(np.int32)
+    got = m.lookup(dev(q)).cpu().numpy()
+    want = oc.lookup(c, q)
+    assert (got == want).all()
+
+
+def test_hash_build_counts_duplicates(pcc):
+    c = shell_coords(pcc)
+    dup = np.concatenate([c, c[:37]])
+    L = pcc.lib()
+    from pcc_amd._lib import ptr, check, stream
+    cap = L.pcc_hash_capacity(dup.shape[0])
+    keys = torch.empty(cap, dtype=torch.int64, device=DEV)
+    vals = torch.empty(cap, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    d = dev(dup)
+    check(L.pcc_hash_build(ptr(d), dup.shape[0], ptr(keys), ptr(vals), cap, ptr(cnt), stream()))
+    assert int(cnt.item()) == 37
+
+
+@pytest.mark.parametrize("ts", [1, 2, 8])
+def test_stride_map(pcc, ts):
+    c = shell_coords(pcc, batch=2) * np.array([1, ts, ts, ts], dtype=np.int32)
+    c[:5, 1:] -= 3 * ts                                  # negative coordinates: true floor division
+    m = pcc.CoordMap(dev(c), ts)
+    d = m.down()
+    want = oc.stride_map(c, ts)
+    got = d.coords.cpu().numpy()
+    assert got.shape[0] == want.shape[0] and as_set(got) == as_set(want)
+    assert d.stride == 2 * ts
+    # the table returned with the map indexes the output rows
+    assert (d.lookup(d.coords).cpu().numpy() == np.arange(got.shape[0])).all()
+
+
+@pytest.mark.parametrize("ksize", [2, 3])
+def test_children(pcc, ksize):
+    c = shell_coords(pcc, grid=24, radius=9.0) * np.array([1, 8, 8, 8], dtype=np.int32)
+    m = pcc.CoordMap(dev(c), 8)
+    u = m.up(ksize)
+    want = oc.children(c, 8, ksize)
+    got = u.coords.cpu().numpy()
+    assert got.shape[0] == want.shape[0] and as_set(got) == as_set(want)
+    assert u.stride == 4
+    assert (u.lookup(u.coords).cpu().numpy() == np.arange(got.shape[0])).all()
+    if ksize == 2:      # offset-major order: children of offset k form one contiguous block
+        n = c.shape[0]
+        offs = oc.kernel_offsets(2) * 4
+        for k in range(8):
+            assert (got[k * n:(k + 1) * n, 1:] == c[:, 1:] + offs[k]).all()
+
+
+def _nbr_as_coords(nbr, in_coords):
+    """Replace row ids by coordinates so tables over differently ordered maps compare."""
+    out = np.full(nbr.shape + (4,), -99999, dtype=np.int64)
+    hit = nbr >= 0
+    out[hit] = in_coords[nbr[hit]]
+    return out
+
+
+@pytest.mark.parametrize("case", ["same", "down", "up3", "up2", "cross"])
+def test_kernel_map(pcc, case):
+    c = shell_coords(pcc, grid=40, radius=15.0) * np.array([1, 4, 4, 4], dtype=np.int32)
+    m = pcc.CoordMap(dev(c), 4)
+    if case == "same":
+        out, ks, tr, step = m, 3, False, 4
+        want_out = c
+    elif case == "down":
+        out, ks, tr, step = m.down(), 3, False, 4
+    elif case == "up3":
+        out, ks, tr, step = m.up(3), 3, True, 2
+    elif case == "up2":
+        out, ks, tr, step = m.up(2), 2, True, 2
+    else:   # stride-1 conv evaluated at a different coordinate set of the same stride
+        sub = c[::3] + np.array([0, 4, 0, 0], dtype=np.int32)
+        out, ks, tr, step = pcc.CoordMap(dev(sub), 4), 3, False, 4
+    out_c = out.coords.cpu().numpy()
+    nbr, gmask = m.kernel_map(out, ks, tr)
+    nbr = nbr.cpu().numpy()
+    want = oc.kernel_map(c, out_c, ks, step, transposed=tr)
+    assert (_nbr_as_coords(nbr, c) == _nbr_as_coords(want, c)).all()
+    # group masks: bit k set iff some row of the 64-row group has offset k
+    gm = gmask.cpu().numpy().view(np.uint32)
+    K = ks ** 3
+    for g in range(gm.shape[0]):
+        rows = nbr[g * 64:(g + 1) * 64]
+        bits = 0
+        for k in range(K):
+            if (rows[:, k] >= 0).any():
+                bits |= 1 << k
+        assert int(gm[g]) == bits
+
+
+CONV_SHAPES = [
+    # cin, cout, ksize  (every (C_in, C_out) pair of configs/Ours.yaml)
+    (128, 128, 3), (64, 128, 3), (128, 256, 3), (128, 64, 3), (64, 64, 3), (64, 32, 3), (32, 3, 3),
+    (128, 2, 3), (64, 2, 3), (192, 256, 3), (128, 1, 3), (128, 128, 1), (16, 16, 1),
+    (4, 64, 3), (4, 2, 3), (2, 2, 3), (2, 128, 3), (2, 16, 3), (16, 2, 3), (1, 1, 3),
+]
+
+
+@pytest.mark.parametrize("cin,cout,ksize", CONV_SHAPES)
+def test_conv_forward_matches_oracle(pcc, cin, cout, ksize):
+    from pcc_amd import sparse as sp
+    torch.manual_seed(cin * 1000 + cout)
+    c = shell_coords(pcc, grid=40, radius=15.0)
+    n = c.shape[0]
+    m = pcc.CoordMap(dev(c), 1)
+    layer = pcc.MinkowskiConvolution(cin, cout, kernel_size=ksize, stride=1, bias=True, dimension=3)
+    with torch.no_grad():
+        layer.kernel.normal_(0, 1.0 / np.sqrt(cin * 10))
+        layer.bias.normal_(0, 0.1)
+    layer = layer.to(DEV)
+    F = torch.randn(n, cin)
+    film = torch.randn(n, 2 * cout)
+    res = torch.randn(n, cout)
+    W = layer.kernel.detach().cpu()
+    b = layer.bias.detach().cpu()
+    if ksize == 1:
+        base = F @ W + b
+    else:
+        nbr = oc.kernel_map(c, c, ksize, 1)
+        base = on._apply_conv(F, W, b, nbr, n)
+    x = pcc.SparseTensor(dev(F), coordinate_map=m)
+    scale = float(base.abs().max())
+    # plain
+    got = layer(x).F.cpu()
+    assert torch.allclose(got, base, rtol=1e-4, atol=2e-5 * scale), float((got - base).abs().max())
+    # fused epilogues: FiLM (no activation), ReLU + residual, LeakyReLU
+    got = layer(x, film=dev(film)).F.cpu()
+    want = base * film[:, :cout] + film[:, cout:]
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-4 * scale)
+    got = layer(x, act=sp.ACT_RELU, residual=dev(res)).F.cpu()
+    assert torch.allclose(got, torch.relu(base) + res, rtol=1e-4, atol=2e-5 * scale)
+    got = layer(x, act=sp.ACT_LRELU).F.cpu()
+    assert torch.allclose(got, torch.nn.functional.leaky_relu(base, 0.01), rtol=1e-4, atol=2e-5 * scale)
+
+
+@pytest.mark.parametrize("kind", ["down", "up3", "up2"])
+def test_strided_and_transposed_conv(pcc, kind):
+    torch.manual_seed(7)
+    c = shell_coords(pcc, grid=40, radius=15.0) * np.array([1, 2, 2, 2], dtype=np.int32)
+    n = c.shape[0]
+    cin, cout = 64, 128
+    F = torch.randn(n, cin)
+    x_o = on.SparseTensor(c, F, 2)
+    if kind == "down":
+        layer = pcc.MinkowskiConvolution(cin, cout, kernel_size=3, stride=2, bias=True, dimension=3)
+    else:
+        layer = pcc.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=int(kind[-1]), stride=2, bias=True, dimension=3)
+    layer = layer.to(DEV)
+    W, b = layer.kernel.detach().cpu(), layer.bias.detach().cpu()
+    want = on.conv(x_o, W, b, 3, 2) if kind == "down" else on.conv_transpose_generative(x_o, W, b, int(kind[-1]))
+    got = layer(pcc.SparseTensor(dev(F), coordinate_map=pcc.CoordMap(dev(c), 2)))
+    assert got.map.stride == want.stride
+    gc, gf = got.C.cpu().numpy(), got.F.cpu()
+    idx = oc.lookup(want.C, gc)
+    assert (idx >= 0).all() and gc.shape[0] == want.C.shape[0]
+    wf = want.F[torch.from_numpy(idx)]
+    assert torch.allclose(gf, wf, rtol=1e-4, atol=2e-5 * float(wf.abs().max()))
+
+
+def test_conv_is_row_order_invariant_bitwise(pcc):
+    """The property the reference's Sorted* shims exist for (entropy_models.py:12-102): a row's
+    result must not depend on where the row sits."""
+    torch.manual_seed(11)
+    c = shell_coords(pcc, grid=40, radius=15.0)
+    n = c.shape[0]
+    F = torch.randn(n, 128)
+    layer = pcc.MinkowskiConvolution(128, 128, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
+    a = layer(pcc.SparseTensor(dev(F), coordinate_map=pcc.CoordMap(dev(c), 1))).F.cpu()
+    perm = np.random.default_rng(5).permutation(n)
+    b = layer(pcc.SparseTensor(dev(F[torch.from_numpy(perm)]), coordinate_map=pcc.CoordMap(dev(c[perm]), 1))).F.cpu()
+    assert torch.equal(a[torch.from_numpy(perm)], b)
+
+
+def test_gather_scatter_compact(pcc):
+    from pcc_amd import sparse as sp
+    rng = np.random.default_rng(2)
+    n, cch = 5000, 6
+    src = torch.randn(n, cch)
+    idx = rng.integers(-1, n, 7000).astype(np.int32)
+    got = sp.gather_rows(dev(src), dev(idx)).cpu()
+    want = torch.zeros(7000, cch)
+    hit = idx >= 0
+    want[torch.from_numpy(hit)] = src[torch.from_numpy(idx[hit].astype(np.int64))]
+    assert torch.equal(got, want)
+    base = torch.randn(7000, cch)
+    acc = dev(base.clone())
+    sp.gather_rows(dev(src), dev(idx), out=acc, accumulate=True)
+    assert torch.equal(acc.cpu(), base + want)
+    perm = rng.permutation(n).astype(np.int32)
+    sc = sp.scatter_rows(dev(src), dev(perm), n).cpu()
+    assert torch.equal(sc[torch.from_numpy(perm.astype(np.int64))], src)
+    mask = rng.random(n) < 0.3
+    coords = np.concatenate([np.zeros((n, 1)), rng.integers(0, 100, (n, 3))], axis=1).astype(np.int32)
+    oc_, of_, ni, m = sp.compact_rows(dev(mask.astype(np.uint8)), dev(coords), dev(src), want_index=True)
+    assert m == int(mask.sum())
+    assert (oc_.cpu().numpy() == coords[mask]).all() and torch.equal(of_.cpu(), src[torch.from_numpy(mask)])
+    ni = ni.cpu().numpy()
+    assert (ni[~mask] == -1).all() and (ni[mask] == np.arange(m)).all()
+    # empty / full masks
+    assert sp.compact_rows(dev(np.zeros(n, np.uint8)), dev(coords), dev(src))[3] == 0
+    assert sp.compact_rows(dev(np.ones(n, np.uint8)), dev(coords), dev(src))[3] == n
+
+
+@pytest.mark.parametrize("nbatch", [1, 3])
+def test_topk_mask(pcc, nbatch):
+    from pcc_amd import sparse as sp
+    from oracle.codec import topk_mask
+    rng = np.random.default_rng(4)
+    c = shell_coords(pcc, batch=nbatch, seed=9)
+    n = c.shape[0]
+    logits = rng.normal(size=(n, 5)).astype(np.float32)
+    logits[rng.integers(0, n, n // 3), 0] = 0.25            # many exact ties -> coordinate-key tie break
+    logits[rng.integers(0, n, 50), 0] = -0.0
+    counts = [int((c[:, 0] == b).sum()) for b in range(nbatch)]
+    for ks in ([cnt // 3 for cnt in counts], [1] * nbatch, [cnt + 5 for cnt in counts], [0] * nbatch, counts):
+        got = sp.topk_mask(dev(logits), dev(c), ks, nbatch).cpu().numpy().astype(bool)
+        want = topk_mask(on.SparseTensor(c, torch.from_numpy(logits), 1), ks)
+        assert (got == want).all(), (ks, int(got.sum()), int(want.sum()))
+
+
+def test_sort_permutation(pcc):
+    c = shell_coords(pcc, batch=3, seed=1)
+    perm = pcc.CoordMap(dev(c), 1).sort_permutation().cpu().numpy()
+    assert (perm == oc.sort_order(c)).all()
+
+
+def test_count_per_batch(pcc):
+    c = shell_coords(pcc, batch=3, seed=1)
+    assert pcc.CoordMap(dev(c), 1).count_per_batch() == oc.count_per_batch(c)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_entropy_bottleneck_kernels(pcc, seeded_state_dict, oracle_codec):
+    model = pcc.synthetic.make_model(0, DEV)
+    model.update()
+    eb = model.entropy_model.entropy_bottleneck
+    o = oracle_codec.eb
+    # tables are built by the same published algorithm on both sides: bit-exact
+    cdf, cdf_len, off = eb.tables()
+    assert (cdf == o.cdf).all() and (cdf_len == o.cdf_length).all() and (off == o.offset).all()
+    torch.manual_seed(0)
+    z = torch.randn(300, 128) * 4
+    z[0, :] = 40.0          # beyond the table: escape-coded
+    z[1, :] = -37.5         # half-way cases: round-half-even
+    zin = z.t().unsqueeze(0).contiguous()
+    want_hat, want_lik = o.forward_eval(zin)
+    got_hat, got_lik = eb(dev(zin))
+    assert torch.equal(got_hat.cpu(), want_hat)
+    assert torch.allclose(got_lik.cpu(), want_lik, rtol=2e-4, atol=1e-9)
+    strings = eb.compress(dev(zin))
+    assert strings[0] == o.compress(zin)[0]                   # byte-identical stream
+    back = eb.decompress(strings, [300]).cpu()
+    assert torch.equal(back, want_hat)
+
+
+def test_gaussian_conditional_kernels(pcc, oracle_codec):
+    model = pcc.synthetic.make_model(0, DEV)
+    model.update()
+    gc = model.entropy_model.gaussian_conditional
+    o = oracle_codec.gc
+    cdf, cdf_len, off = gc.tables()
+    assert (cdf == o.cdf).all() and (cdf_len == o.cdf_length).all() and (off == o.offset).all()
+    torch.manual_seed(1)
+    n, c = 700, 128
+    y = torch.randn(n, c) * 3
+    scales = torch.exp(torch.randn(n, c) * 2)                 # spans the whole table, incl. < 0.11
+    scales[0] = -1.0
+    scales[1] = torch.tensor(o.scale_table[5].item())          # exactly on a threshold
+    means = torch.randn(n, c)
+    y[2] = 1e4                                                # long escapes
+    params = torch.cat([scales, means], dim=1)
+    s3, m3, y3 = (t.t().unsqueeze(0).contiguous() for t in (scales, means, y))
+    want_idx = o.build_indexes(s3)
+    got_idx = gc.build_indexes(dev(s3)).cpu()
+    assert torch.equal(got_idx, want_idx)
+    want_hat, want_lik = o.forward_eval(y3, s3, m3)
+    got_hat, got_lik = gc(dev(y3), dev(s3), means=dev(m3))
+    assert torch.equal(got_hat.cpu(), want_hat)
+    # difference of two erfc values: absolute error is a few ulp of 1.0
+    assert torch.allclose(got_lik.cpu(), want_lik, rtol=5e-4, atol=3e-7)
+    strings = gc.compress_features(dev(y), dev(params))
+    assert strings[0] == o.compress(y3, want_idx, m3)[0]
+    back = gc.decompress_features(strings, dev(params), c).cpu()
+    assert torch.equal(back.t().unsqueeze(0), o.decompress(strings, want_idx, m3))
