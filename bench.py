@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: ColorModel.compress + decompress of one 10-bit frame per step.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL).  Frames are independent
+  units (the codec is intra-only), so rank r codes its own frame each step (weak scaling, no
+  data-path collective inside the codec) and the per-frame bitstreams are all-gathered over
+  RCCL at the end of every step, as a whole-sequence encoder would collect them.
+
+Metric (BASELINE.json): encode+decode Mpoints/s = points coded / (t_enc + t_dec), inputs resident
+in HBM, in-memory API (strings returned; train.py:251-257), timing bracket as utils.py:448-464.
+Workload: SURVEY.md §8d config 2 — synthetic 10-bit sphere shell, N = 850,824 (longdress_vox10_1300
+has 857,966 points), q = (0.5, 0.5), seeded random weights of configs/Ours.yaml (no trained
+weights are published).  All arithmetic fp32.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "mid"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", default="256,100,0.5", help="grid,radius,half_width of the CPU-baseline shell")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
+    return ap.parse_args()
+
+
+def cpu_baseline(state_dict, sample):
+    """The oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload."""
+    from oracle.codec import Codec
+    import pcc_amd
+    grid, radius, hw = sample.split(",")
+    pts = pcc_amd.synthetic.sphere_shell(int(grid), float(radius), float(hw))
+    qc, qf = pcc_amd.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    codec = Codec(state_dict)
+    codec.update()
+    t0 = time.time()
+    strings, shape, k, coords = codec.compress(pts, qc, qf)
+    t1 = time.time()
+    codec.decompress(coords, strings, shape, k)
+    t2 = time.time()
+    n = pts.shape[0]
+    return {"value": n / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
+            "sample": f"one {grid}^3 sphere-shell frame, N={n} points, q=(0.5,0.5), same weights; "
+                      f"t_enc={t1 - t0:.2f}s t_dec={t2 - t1:.2f}s (torch-CPU sgemm + C rANS oracle)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import pcc_amd
+    from pcc_amd import sparse as sp
+    syn = pcc_amd.synthetic
+    model = syn.make_model(0, dev)
+    model.update()
+
+    cfg = {"config1": syn.CONFIG1, "config2": syn.CONFIG2, "mid": dict(grid=256, radius=100.0, half_width=0.5)}[args.workload]
+    cfg = dict(cfg)
+    cfg["radius"] = cfg["radius"] - 0.25 * rank            # rank r codes its own frame
+    pts = syn.sphere_shell(**cfg)
+    N = pts.shape[0]
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    x = torch.from_numpy(pts).to(dev)
+    q_coords = torch.from_numpy(qc).to(dev)
+    q_feats = torch.from_numpy(qf).to(dev)
+
+    def gather_bitstreams(strings):
+        payload = strings[0][0] + strings[1][0]
+        lens = torch.zeros(world, dtype=torch.int64, device=dev)
+        mine = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(lens, mine)
+        mx = int(lens.max().item())
+        buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
+        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+        out = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(out, buf)
+        return out, lens
+
+    t_enc = t_dec = 0.0
+    last = {}
+
+    def step(timed):
+        nonlocal t_enc, t_dec
+        Q = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)   # fresh maps every step
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        strings, shape, k, coords = model.compress(x, Q)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if world > 1:
+            gather_bitstreams(strings)
+        if timed:
+            t_enc += t1 - t0
+            t_dec += t2 - t1
+        last.update(strings=strings, rec=rec, k=k)
+
+    for _ in range(args.warmup):
+        step(False)
+
+    sp.PROFILER = []
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    prof, sp.PROFILER = sp.PROFILER, None
+
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        ntot = torch.tensor([N], dtype=torch.int64, device=dev)
+        dist.all_reduce(ntot)
+        n_total = int(ntot.item())
+    else:
+        n_total = N
+
+    # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
+    classes = {}
+    pop_cache = {}
+
+    def active_slots(gmask, n_out):
+        """sum over 64-row groups of the number of kernel offsets the group executes"""
+        if gmask is None:
+            return (n_out + 31) // 32
+        key = gmask.data_ptr()
+        if key not in pop_cache:
+            g = gmask.to(torch.int64) & 0xFFFFFFFF
+            pop_cache[key] = int(sum(((g >> i) & 1).sum() for i in range(27)).item())
+        return pop_cache[key]
+
+    for name, cin, cout, pairs, n_out, e0, e1, gmask in prof:
+        p = int(pairs.item()) if torch.is_tensor(pairs) else int(pairs)
+        c = classes.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, gather_bytes=0.0, exec_flops=0.0))
+        c["exec_flops"] += 2.0 * 32 * active_slots(gmask, n_out) * cin * ((cout + 31) // 32 * 32)
+        c["launches"] += 1
+        c["ms"] += e0.elapsed_time(e1)
+        c["flops"] += 2.0 * p * cin * cout
+        c["gather_bytes"] += 4.0 * (p * cin + n_out * cout)
+    dom_name = max(classes, key=lambda n: classes[n]["ms"]) if classes else None
+    roofline = None
+    if dom_name:
+        d = classes[dom_name]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "launches_per_step": d["launches"] / args.steps,
+                    "avg_launch_ms": d["ms"] / d["launches"],
+                    "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                    "share_of_step_time": d["ms"] * 1e-3 / elapsed}
+    if args.breakdown and rank == 0:
+        tot_ms = sum(c["ms"] for c in classes.values())
+        for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
+            print(f"  {n_:16s} launches/step {c['launches'] / args.steps:6.1f}  ms/step {c['ms'] / args.steps:8.2f} "
+                  f"GFLOP/step {c['flops'] / args.steps / 1e9:9.1f}  TFLOP/s {c['flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}"
+                  f"  issued-MFMA TFLOP/s {c['exec_flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}",
+                  file=sys.stderr)
+        print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "
+              f"t_enc {t_enc / args.steps * 1e3:.1f} ms  t_dec {t_dec / args.steps * 1e3:.1f} ms", file=sys.stderr)
+
+    from oracle.codec import count_bits       # pure-python bit counter (utils.py:30-51); checker side only
+    bpp = count_bits(last["strings"]) / N
+    out = {
+        "metric": "encode+decode Mpoints/sec",
+        "value": n_total * args.steps / elapsed / 1e6,
+        "unit": "Mpoints/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {cfg['grid']}^3 voxel sphere shell r={cfg['radius']}, N={N} points/frame, "
+                               "q=(0.5,0.5), configs/Ours.yaml, seeded random weights, in-memory compress+decompress, "
+                               "one frame per rank per step",
+                   "points_per_frame": N, "parallelism": f"frames x{world}" if world > 1 else "single"},
+        "t_enc_ms": t_enc / args.steps * 1e3,
+        "t_dec_ms": t_dec / args.steps * 1e3,
+        "bpp": bpp,
+        "conv_gflop_per_step": sum(c["flops"] for c in classes.values()) / args.steps / 1e9,
+        "roofline": roofline,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sd = {n_: t.detach().cpu() for n_, t in model.state_dict().items()}
+        out["cpu_baseline"] = cpu_baseline(sd, args.cpu_sample)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,11 +89,27 @@ int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, ui
  * kernel offset k, nbr[j*K + k] = input row at c_out + sign * off_k * step, or -1.
  * sign = +1 for (strided) convolution with step = input tensor stride; sign = -1 for
  * transposed / generative convolution with step = input stride / 2.
- * group_mask[g] (uint32, one per 64 output rows) has bit k set iff some row of the
- * group has a neighbour at offset k (used by pcc_conv_fwd to skip empty work). */
+ * row_mask[j] (uint32) has bit k set iff output row j has a neighbour at offset k.
+ * *pair_count (device int64, may be NULL) receives the number of (output row, offset) pairs
+ * with a neighbour = the "pairs" of the algorithmic FLOP count 2 * pairs * C_in * C_out. */
 int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys,
                    const int32_t* in_vals, int64_t in_cap, int32_t ksize, int32_t step,
-                   int32_t sign, int32_t* nbr, uint32_t* group_mask, void* stream);
+                   int32_t sign, int32_t* nbr, uint32_t* row_mask, int64_t* pair_count,
+                   void* stream);
+
+/* Execution order for the MFMA convolution.  Output rows are sorted by
+ * (spatial block of 2^block_log2 voxels per axis, neighbour mask); block_log2 < 0 sorts by
+ * mask alone.  Rows with the same neighbour pattern become adjacent, so a 32-row MFMA tile
+ * multiplies (almost) no all-zero neighbour rows.  Results do not depend on the order.
+ *   order[p]        = output row executed at position p
+ *   nbr_sorted[p,:] = nbr[order[p],:]
+ *   group_mask32[g] = OR of row_mask over positions 32g .. 32g+31
+ * scratch_bytes from pcc_order_scratch_bytes(n). */
+int64_t pcc_order_scratch_bytes(int64_t n);
+int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int64_t n,
+                           int32_t block_log2, int32_t tensor_stride, const int32_t* nbr, int32_t K,
+                           int32_t* order, int32_t* nbr_sorted, uint32_t* group_mask32,
+                           void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sparse convolution forward (ME.MinkowskiConvolution / *ConvolutionTranspose forward,
@@ -106,14 +122,18 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
  * W is the ME kernel tensor [K, cin, cout] (fp32).  For cin % 32 == 0 the MFMA path is used
  * and needs `w_packed` from pcc_conv_pack_weights; otherwise (cin in {1,2,4,8,16}) the
  * thin path reads `w` directly.  nbr == NULL means kernel_size 1 (identity map, K = 1).
+ * MFMA path: if `order` != NULL, `nbr` is the permuted table and `group_mask32` the masks from
+ * pcc_order_rows_by_mask, and position p computes output row order[p]; with order == NULL rows
+ * run in natural order (group_mask32 may then be NULL = every offset executed).
+ * film / residual / fout are always indexed by the output row, never by the position.
  * ------------------------------------------------------------------------------------- */
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, float* w_packed,
                           void* stream);
 int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed,
-                 const float* bias, const int32_t* nbr, const uint32_t* group_mask, int32_t K,
-                 float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film,
-                 const float* residual, void* stream);
+                 const float* bias, const int32_t* nbr, const int32_t* order,
+                 const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
+                 int32_t act, const float* film, const float* residual, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row movement: lookup-gather, pruning.

@@ -26,8 +26,9 @@ struct ConvArgs {
     const float* w;       // raw [K, cin, cout] (thin path)
     const float* wp;      // packed [K, cinp/4, coutp, 4] (MFMA path)
     const float* bias;    // [cout] or null
-    const int32_t* nbr;   // [n_out, K] or null (identity)
-    const uint32_t* gmask;  // [ceil(n_out/64)] or null (all offsets active)
+    const int32_t* nbr;   // [n_out, K] or null (identity); permuted by `order` on the MFMA path
+    const int32_t* order;   // [n_out] execution position -> output row, or null (natural order)
+    const uint32_t* gmask;  // [ceil(n_out/32)] offsets live per 32 positions, or null (all live)
     float* fout;
     const float* film;      // [n_out, 2*cout] or null
     const float* residual;  // [n_out, cout] or null
@@ -93,21 +94,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int CCH = a.cin / 32;
     const int K = a.K;
 
-    // which kernel offsets are live for this tile / for this wave's rows
-    uint32_t tmask, wmask;
+    // which kernel offsets are live for this tile / for each of this wave's 32-row MFMA tiles
+    uint32_t tmask, mmask[MT];
     {
         const uint32_t all = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
         if (a.gmask) {
-            const int64_t g0 = row0 >> 6;
-            const int64_t ng = (a.n_out + 63) >> 6;
-            const uint32_t m0 = a.gmask[g0] & all;
-            const uint32_t m1 = (g0 + 1 < ng) ? (a.gmask[g0 + 1] & all) : 0u;
-            tmask = m0 | m1;
-            if (WM == 64) wmask = (wrow == 0) ? m0 : m1;
-            else wmask = (wrow < 64) ? m0 : m1;
+            const int64_t g0 = row0 >> 5;
+            const int64_t ng = (a.n_out + 31) >> 5;
+            tmask = 0u;
+#pragma unroll
+            for (int g = 0; g < BM / 32; ++g) tmask |= (g0 + g < ng) ? (a.gmask[g0 + g] & all) : 0u;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int64_t g = g0 + (wrow >> 5) + m;
+                const uint32_t v = (g < ng) ? (a.gmask[g] & all) : 0u;
+                mmask[m] = __builtin_amdgcn_readfirstlane(v);    // wave-uniform by construction
+            }
         } else {
-            tmask = wmask = all;
+            tmask = all;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) mmask[m] = all;
         }
+        tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
 
     f32x16 acc[MT][NT];
@@ -122,23 +130,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int grow = t >> 3, gchunk = t & 7;
     int idx_cur[4], idx_nxt[4];
     f32x4 areg[4];
+    bool amask[4];
     f32x4 wreg[W_LOADS];
 
     auto load_idx = [&](int k, int (&dst)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            // branch-free: read a clamped row, then mask (conditional loads make hipcc wait for the
+            // data at the join, which serialises the gather behind the MFMAs)
             const int64_t row = row0 + grow + 32 * i;
-            int v = -1;
-            if (row < a.n_out) v = a.nbr ? a.nbr[row * K + k] : (int)row;
-            dst[i] = v;
+            const int64_t rs = row < a.n_out ? row : a.n_out - 1;
+            const int v = a.nbr ? a.nbr[rs * K + k] : (int)rs;
+            dst[i] = row < a.n_out ? v : -1;
         }
     };
     auto load_step = [&](int k, int c, const int (&idx)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (idx[i] >= 0) v = *reinterpret_cast<const f32x4*>(a.fin + (int64_t)idx[i] * a.cin + c * 32 + gchunk * 4);
-            areg[i] = v;
+            // absent neighbours read row 0 (always valid, L1-resident) and are zeroed in store_step
+            const int64_t src = idx[i] < 0 ? 0 : idx[i];
+            areg[i] = *reinterpret_cast<const f32x4*>(a.fin + src * a.cin + c * 32 + gchunk * 4);
+            amask[i] = idx[i] >= 0;
         }
         const float* wbase = a.wp + (((int64_t)k * (a.cin / 4) + c * 8) * a.coutp + nt * BN) * 4;
 #pragma unroll
@@ -152,29 +164,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         float* Ab = As + buf * A_ELEMS;
         float* Wb = Ws + buf * W_ELEMS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Ab + (grow + 32 * i) * A_LD + gchunk * 4) = areg[i];
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+            *reinterpret_cast<f32x4*>(Ab + (grow + 32 * i) * A_LD + gchunk * 4) = amask[i] ? areg[i] : z;
+        }
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<f32x4*>(Wb + (t + 256 * j) * 4) = wreg[j];
     };
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int k) {
         const float* Ab = As + buf * A_ELEMS;
         const float* Wb = Ws + buf * W_ELEMS;
+        bool live[MT];
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) { live[m] = (mmask[m] >> k) & 1u; any |= live[m]; }
+        if (!any) return;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            f32x4 av[MT], bv[NT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-                av[m] = *reinterpret_cast<const f32x4*>(Ab + (wrow + 32 * m + r) * A_LD + 8 * kk + 4 * h);
+            f32x4 bv[NT];
 #pragma unroll
             for (int n = 0; n < NT; ++n)
                 bv[n] = *reinterpret_cast<const f32x4*>(Wb + ((2 * kk + h) * BN + wcol + 32 * n + r) * 4);
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int m = 0; m < MT; ++m) {
+                if (!live[m]) continue;      // wave-uniform: no row of this 32-row tile has offset k
+                const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (wrow + 32 * m + r) * A_LD + 8 * kk + 4 * h);
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
+                for (int s = 0; s < 4; ++s)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][s], bv[n][s], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[n][s], acc[m][n], 0, 0, 0);
+            }
         }
     };
 
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 if (nc == 0) load_step(nk, 0, idx_nxt);
                 else load_step(nk, nc, idx_cur);
             }
-            if ((wmask >> k) & 1u) compute(cur);
+            compute(cur, k);
             if (has_next) store_step(cur ^ 1);
             __syncthreads();
             if (!has_next) break;
@@ -224,8 +244,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const float bcol = a.bias ? a.bias[col] : 0.0f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int64_t row = row0 + wrow + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                if (row >= a.n_out) continue;
+                const int64_t pos = row0 + wrow + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (pos >= a.n_out) continue;
+                const int64_t row = a.order ? a.order[pos] : pos;
                 float v = acc[m][n][reg] + bcol;
                 if (a.film) {
                     const float* fr = a.film + row * (2 * (int64_t)a.cout);
@@ -324,14 +345,14 @@ int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, 
 }
 
 int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
-                 const int32_t* nbr, const uint32_t* group_mask, int32_t K, float* fout, int64_t n_out, int32_t cout,
-                 int32_t act, const float* film, const float* residual, void* stream) {
+                 const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
+                 int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
     PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd: K=%d out of range", K);
     PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd: nbr == NULL needs K == 1 and n_in == n_out");
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation %d", act);
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
-    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.gmask = group_mask; a.fout = fout;
+    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout;
     a.film = film; a.residual = residual; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout;
     a.coutp = round_up32(cout); a.K = K; a.act = act;
     hipStream_t st = as_stream(stream);

@@ -296,17 +296,20 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
                                                          const uint64_t* __restrict__ keys,
                                                          const int32_t* __restrict__ vals, uint64_t mask, int ks,
                                                          int K, int step, int32_t* __restrict__ nbr,
-                                                         uint32_t* __restrict__ group_mask) {
+                                                         uint32_t* __restrict__ row_mask,
+                                                         unsigned long long* __restrict__ pair_count) {
     __shared__ int4 rows[64];
-    __shared__ unsigned gm;
+    __shared__ unsigned rm[64];
+    __shared__ unsigned hits_s;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     if (threadIdx.x < 64) {
         const int64_t r = row0 + threadIdx.x;
         rows[threadIdx.x] = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
     }
-    if (threadIdx.x == 0) gm = 0u;
+    if (threadIdx.x < 64) rm[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) hits_s = 0u;
     __syncthreads();
-    unsigned mybits = 0u;
+    unsigned myhits = 0u;
     const int total = 64 * K;
     for (int e = threadIdx.x; e < total; e += 256) {
         const int lr = e / K, k = e - lr * K;
@@ -317,11 +320,12 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
         const int4 c = rows[lr];
         const int idx = table_find(keys, vals, mask, pack_key(c.x, c.y + dx * step, c.z + dy * step, c.w + dz * step));
         nbr[r * K + k] = idx;
-        if (idx >= 0) mybits |= (1u << k);
+        if (idx >= 0) { atomicOr(&rm[lr], 1u << k); ++myhits; }
     }
-    if (mybits) atomicOr(&gm, mybits);
+    if (myhits) atomicAdd(&hits_s, myhits);
     __syncthreads();
-    if (threadIdx.x == 0 && group_mask) group_mask[blockIdx.x] = gm;
+    if (row_mask && threadIdx.x < 64 && row0 + threadIdx.x < n_out) row_mask[row0 + threadIdx.x] = rm[threadIdx.x];
+    if (threadIdx.x == 0 && pair_count && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -463,15 +467,17 @@ int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, ui
 }
 
 int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals,
-                   int64_t in_cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* group_mask,
-                   void* stream) {
+                   int64_t in_cap, int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* row_mask,
+                   int64_t* pair_count, void* stream) {
     PCC_REQUIRE(ksize >= 1 && ksize <= 3, "pcc_kernel_map: kernel size must be 1..3");
     PCC_REQUIRE(sign == 1 || sign == -1, "pcc_kernel_map: sign must be +1/-1");
     PCC_REQUIRE(in_cap > 0 && (in_cap & (in_cap - 1)) == 0, "pcc_kernel_map: bad capacity");
+    if (pair_count) PCC_CHECK_HIP(hipMemsetAsync(pair_count, 0, sizeof(int64_t), as_stream(stream)));
     if (n_out <= 0) return PCC_OK;
     const int K = ksize * ksize * ksize;
     hipLaunchKernelGGL(kernel_map_kernel, dim3(blocks_for(n_out, 64)), dim3(256), 0, as_stream(stream), out_coords,
-                       n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), ksize, K, sign * step, nbr, group_mask);
+                       n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), ksize, K, sign * step, nbr, row_mask,
+                       reinterpret_cast<unsigned long long*>(pair_count));
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

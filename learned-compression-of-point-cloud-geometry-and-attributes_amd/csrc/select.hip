@@ -152,6 +152,51 @@ __global__ __launch_bounds__(256) void coords_to_keys(const int32_t* __restrict_
 
 static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
+// ---- execution order of a kernel map's output rows -------------------------------------------
+// key = (spatial block id << 27) | 27-bit neighbour mask; rows with equal masks become adjacent
+// so that 32-row MFMA tiles execute (almost) only offsets every row of the tile has.
+__global__ __launch_bounds__(256) void order_keys_kernel(const uint32_t* __restrict__ row_mask,
+                                                         const int32_t* __restrict__ coords, int64_t n,
+                                                         int block_log2, int ts, uint64_t* __restrict__ keys,
+                                                         int32_t* __restrict__ iota) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = row_mask[i] & 0x7FFFFFFu;
+    if (block_log2 >= 0) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        const uint64_t bx = (uint64_t)(((c.y / ts) + 512) >> block_log2) & 0x3FF;
+        const uint64_t by = (uint64_t)(((c.z / ts) + 512) >> block_log2) & 0x3FF;
+        const uint64_t bz = (uint64_t)(((c.w / ts) + 512) >> block_log2) & 0x3FF;
+        key |= ((((uint64_t)(c.x & 0x3F) << 30) | (bx << 20) | (by << 10) | bz) << 27);
+    }
+    keys[i] = key;
+    iota[i] = (int32_t)i;
+}
+
+// one wave per 32 sorted rows?  simpler: one thread per (sorted row, offset) for the table gather,
+// group masks reduced with a wave-level OR over each aligned 32-lane half.
+__global__ __launch_bounds__(256) void order_apply_kernel(const int32_t* __restrict__ order,
+                                                          const uint32_t* __restrict__ row_mask,
+                                                          const int32_t* __restrict__ nbr, int64_t n, int K,
+                                                          int32_t* __restrict__ nbr_sorted,
+                                                          uint32_t* __restrict__ group_mask32) {
+    // part 1: group masks (threads 0..n-1 of the grid, one per sorted row)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    uint32_t m = (i < n) ? row_mask[order[i]] : 0u;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
+    if (i < n && (threadIdx.x & 31) == 0) group_mask32[i >> 5] = m;
+    // part 2: permuted neighbour table, 256 rows per block, coalesced on the destination
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t rows = (n - r0 < 256) ? (n - r0) : 256;
+    const int64_t total = rows * K;
+    for (int64_t e = threadIdx.x; e < total; e += 256) {
+        const int64_t lr = e / K;
+        const int k = (int)(e - lr * K);
+        nbr_sorted[(r0 + lr) * K + k] = nbr[(int64_t)order[r0 + lr] * K + k];
+    }
+}
+
 }  // namespace pcc
 
 using namespace pcc;
@@ -175,6 +220,33 @@ int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_
         hipLaunchKernelGGL(topk_write_mask, dim3(blocks_for(n, 256)), dim3(256), 0, st, logits, ld, coords, n, nbatch,
                            state, mask);
     }
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int64_t pcc_order_scratch_bytes(int64_t n) { return pcc_sort_scratch_bytes(n); }
+
+int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
+                           int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
+                           uint32_t* group_mask32, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (n <= 0) return PCC_OK;
+    PCC_REQUIRE(n < (1ll << 31), "pcc_order_rows_by_mask: too many rows");
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_order_rows_by_mask: K out of range");
+    PCC_REQUIRE(block_log2 < 0 || coords != nullptr, "pcc_order_rows_by_mask: block ordering needs coordinates");
+    PCC_REQUIRE(tensor_stride >= 1, "pcc_order_rows_by_mask: bad tensor stride");
+    PCC_REQUIRE(scratch_bytes >= pcc_sort_scratch_bytes(n), "pcc_order_rows_by_mask: scratch too small");
+    hipStream_t st = as_stream(stream);
+    char* p = reinterpret_cast<char*>(scratch);
+    uint64_t* keys_in = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
+    uint64_t* keys_out = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
+    int32_t* iota = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
+    size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
+    hipLaunchKernelGGL(order_keys_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, coords, n, block_log2,
+                       tensor_stride, keys_in, iota);
+    const int end_bit = block_log2 >= 0 ? 64 : 27;
+    PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(p, temp, keys_in, keys_out, iota, order, (int)n, 0, end_bit, st));
+    hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
+                       nbr_sorted, group_mask32);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -113,21 +113,46 @@ class CoordMap:
         return self._cache[key]
 
     def kernel_map(self, out_map, ksize, transposed=False):
-        """(nbr int32 [N_out, K], group_mask) for input=self, output=out_map."""
+        """(nbr int32 [N_out, K], row_mask int32 [N_out], pair_count int64[1]) for input=self, output=out_map."""
         key = ("kmap", id(out_map), ksize, transposed)
         hit = self._cache.get(key)
         if hit is not None and hit[0] is out_map:
-            return hit[1], hit[2]
+            return hit[1:]
         keys, vals, cap = self.table()
         K = ksize ** 3
         n_out = out_map.n
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.device)
-        gmask = torch.empty((n_out + 63) // 64, dtype=torch.int32, device=self.device)
+        row_mask = torch.empty(n_out, dtype=torch.int32, device=self.device)
+        pairs = torch.empty(1, dtype=torch.int64, device=self.device)
         step = self.stride // 2 if transposed else self.stride
         check(_lib.lib().pcc_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step,
-                                        -1 if transposed else 1, ptr(nbr), ptr(gmask), _lib.stream()))
-        self._cache[key] = (out_map, nbr, gmask)   # keeps out_map alive so id() stays unique
-        return nbr, gmask
+                                        -1 if transposed else 1, ptr(nbr), ptr(row_mask), ptr(pairs), _lib.stream()))
+        self._cache[key] = (out_map, nbr, row_mask, pairs)   # keeps out_map alive so id() stays unique
+        return nbr, row_mask, pairs
+
+    def ordered_kernel_map(self, out_map, ksize, transposed=False):
+        """Kernel map in MFMA execution order: (nbr_sorted [N_out, K], order [N_out], group_mask32, pair_count).
+
+        Output rows are sorted by neighbour mask (optionally inside spatial blocks, ORDER_BLOCK_LOG2) so
+        that 32-row MFMA tiles skip the offsets none of their rows has."""
+        key = ("okmap", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] is out_map:
+            return hit[1:]
+        nbr, row_mask, pairs = self.kernel_map(out_map, ksize, transposed)
+        L = _lib.lib()
+        n_out, K = nbr.shape
+        dev = self.device
+        order = torch.empty(n_out, dtype=torch.int32, device=dev)
+        nbr_sorted = torch.empty_like(nbr)
+        gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
+        nbytes = L.pcc_order_scratch_bytes(n_out)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        check(L.pcc_order_rows_by_mask(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
+                                       ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(scratch), nbytes,
+                                       _lib.stream()))
+        self._cache[key] = (out_map, nbr_sorted, order, gmask, pairs)
+        return nbr_sorted, order, gmask, pairs
 
     def count_per_batch(self):
         """AnalysisTransform.count_per_batch (model/transforms.py:65-71)."""
@@ -251,17 +276,49 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     w, wp, bias = layer.weights(out_channels)
     cin = x_feats.shape[1]
     cout = w.shape[-1]
+    order = gmask = None
     if ksize == 1:
-        nbr = gmask = None
+        nbr = pairs = None
         K = 1
+    elif cin % 32 == 0:
+        nbr, order, gmask, pairs = in_map.ordered_kernel_map(out_map, ksize, transposed)
+        K = ksize ** 3
     else:
-        nbr, gmask = in_map.kernel_map(out_map, ksize, transposed)
+        nbr, _, pairs = in_map.kernel_map(out_map, ksize, transposed)
         K = ksize ** 3
     n_out = out_map.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
-    check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(gmask), K,
+    prof = PROFILER
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
                          ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+    if prof is not None:
+        ev1.record()
+        prof.append((conv_kernel_name(cin, cout), cin, cout, pairs if pairs is not None else n_out, n_out, ev0, ev1,
+                     gmask))
     return out
+
+
+# Spatial block size (log2, in voxels of the map's stride) inside which rows are ordered by neighbour
+# mask; -1 = order by mask over the whole map (best MFMA tile occupancy, least gather locality).
+ORDER_BLOCK_LOG2 = -1
+
+# Optional launch log for bench.py: a list that receives one tuple per convolution launch
+# (kernel class, cin, cout, pairs (device scalar or int), n_out, start event, end event).  The
+# events are recorded on the stream the kernel is launched on (torch's current stream).
+PROFILER = None
+
+
+def conv_kernel_name(cin, cout):
+    """Which kernel pcc_conv_fwd dispatches to (mirrors csrc/conv.hip)."""
+    if cin % 32 != 0:
+        return f"conv_thin<{cin}>"
+    coutp = (cout + 31) // 32 * 32
+    bn = 128 if coutp % 128 == 0 else (64 if coutp % 64 == 0 else 32)
+    return f"conv_mfma<{bn}>"
 
 
 # ---------------------------------------------------------------------------------------------

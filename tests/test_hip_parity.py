@@ -129,20 +129,32 @@ def test_kernel_map(pcc, case):
         sub = c[::3] + np.array([0, 4, 0, 0], dtype=np.int32)
         out, ks, tr, step = pcc.CoordMap(dev(sub), 4), 3, False, 4
     out_c = out.coords.cpu().numpy()
-    nbr, gmask = m.kernel_map(out, ks, tr)
+    nbr, row_mask, pairs = m.kernel_map(out, ks, tr)
     nbr = nbr.cpu().numpy()
     want = oc.kernel_map(c, out_c, ks, step, transposed=tr)
     assert (_nbr_as_coords(nbr, c) == _nbr_as_coords(want, c)).all()
-    # group masks: bit k set iff some row of the 64-row group has offset k
-    gm = gmask.cpu().numpy().view(np.uint32)
     K = ks ** 3
-    for g in range(gm.shape[0]):
-        rows = nbr[g * 64:(g + 1) * 64]
-        bits = 0
-        for k in range(K):
-            if (rows[:, k] >= 0).any():
-                bits |= 1 << k
-        assert int(gm[g]) == bits
+    # row masks: bit k set iff the row has a neighbour at offset k; pair count = number of hits
+    want_mask = ((nbr >= 0).astype(np.int64) << np.arange(K)).sum(axis=1)
+    assert (row_mask.cpu().numpy().view(np.uint32).astype(np.int64) == want_mask).all()
+    assert int(pairs.item()) == int((nbr >= 0).sum())
+    # execution order for the MFMA path: a permutation, the permuted table, OR-masks per 32 positions
+    for blk in (-1, 3):
+        from pcc_amd import sparse as sp
+        sp.ORDER_BLOCK_LOG2 = blk
+        try:
+            nbr_s, order, gm, _ = m.ordered_kernel_map(out, ks, tr)
+        finally:
+            sp.ORDER_BLOCK_LOG2 = -1
+        order = order.cpu().numpy()
+        assert sorted(order.tolist()) == list(range(nbr.shape[0]))
+        assert (nbr_s.cpu().numpy() == nbr[order]).all()
+        gm = gm.cpu().numpy().view(np.uint32)
+        sm = want_mask[order]
+        for g in range(gm.shape[0]):
+            assert int(gm[g]) == int(np.bitwise_or.reduce(sm[g * 32:(g + 1) * 32]))
+        if blk < 0:
+            assert (np.diff(sm) >= 0).all()          # sorted by mask
 
 
 CONV_SHAPES = [
