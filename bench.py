@@ -94,17 +94,12 @@ def main():
     q_coords = torch.from_numpy(qc).to(dev)
     q_feats = torch.from_numpy(qf).to(dev)
 
-    def gather_bitstreams(strings):
-        payload = strings[0][0] + strings[1][0]
-        lens = torch.zeros(world, dtype=torch.int64, device=dev)
-        mine = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(lens, mine)
-        mx = int(lens.max().item())
-        buf = torch.zeros(mx, dtype=torch.uint8, device=dev)
-        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-        out = torch.empty(world * mx, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(out, buf)
-        return out, lens
+    from pcc_amd import parallel as par
+
+    def gather_bitstreams(strings, shape, k):
+        # frames are the sharded unit: every rank contributes its frame's container, all ranks end
+        # up with the whole step's bitstreams (RCCL all-gather(v) over xGMI)
+        return par.all_gather_bitstreams(par.pack_unit(strings, shape, k), dev)
 
     t_enc = t_dec = 0.0
     last = {}
@@ -121,7 +116,7 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if world > 1:
-            gather_bitstreams(strings)
+            gather_bitstreams(strings, shape, k)
         if timed:
             t_enc += t1 - t0
             t_dec += t2 - t1
@@ -167,12 +162,16 @@ def main():
             pop_cache[key] = int(sum(((g >> i) & 1).sum() for i in range(27)).item())
         return pop_cache[key]
 
+    launches = []
     for name, cin, cout, pairs, n_out, e0, e1, gmask in prof:
         p = int(pairs.item()) if torch.is_tensor(pairs) else int(pairs)
         c = classes.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, gather_bytes=0.0, exec_flops=0.0))
-        c["exec_flops"] += 2.0 * 32 * active_slots(gmask, n_out) * cin * ((cout + 31) // 32 * 32)
+        ex = 2.0 * 32 * active_slots(gmask, n_out) * cin * ((cout + 31) // 32 * 32)
+        ms = e0.elapsed_time(e1)
+        launches.append((ms, name, cin, cout, n_out, p, ex))
+        c["exec_flops"] += ex
         c["launches"] += 1
-        c["ms"] += e0.elapsed_time(e1)
+        c["ms"] += ms
         c["flops"] += 2.0 * p * cin * cout
         c["gather_bytes"] += 4.0 * (p * cin + n_out * cout)
     dom_name = max(classes, key=lambda n: classes[n]["ms"]) if classes else None
@@ -193,6 +192,10 @@ def main():
                   f"GFLOP/step {c['flops'] / args.steps / 1e9:9.1f}  TFLOP/s {c['flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}"
                   f"  issued-MFMA TFLOP/s {c['exec_flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}",
                   file=sys.stderr)
+        per_step = len(launches) // args.steps
+        for ms, n_, cin, cout, n_out, p, ex in sorted(launches[:per_step], key=lambda t: -t[0])[:16]:
+            print(f"    {n_:14s} {cin:4d}->{cout:<4d} rows {n_out:8d} nbrs/row {p / max(n_out, 1):5.1f}  {ms:7.3f} ms  "
+                  f"alg {2.0 * p * cin * cout / ms / 1e9:6.1f} TF/s  issued {ex / ms / 1e9:6.1f} TF/s", file=sys.stderr)
         print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "
               f"t_enc {t_enc / args.steps * 1e3:.1f} ms  t_dec {t_dec / args.steps * 1e3:.1f} ms", file=sys.stderr)
 

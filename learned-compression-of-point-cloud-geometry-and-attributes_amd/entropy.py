@@ -52,11 +52,14 @@ def _rans_encode(symbols, indexes, cdf, cdf_length, offset):
     symbols = np.ascontiguousarray(symbols, dtype=np.int32).reshape(-1)
     indexes = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
     n = symbols.size
-    cap = 4 * (3 * n + 4)
-    out = np.empty(cap, dtype=np.uint8)
-    nbytes = check(L.pcc_rans_encode_with_indexes(ptr(symbols), ptr(indexes), n, ptr(cdf), cdf.shape[1],
-                                                  ptr(cdf_length), ptr(offset), ptr(out), cap))
-    return out[:nbytes].tobytes()
+    # typical streams need well under 1 byte per symbol; fall back to the worst-case bound if not
+    for cap in (n + 4096, 4 * (3 * n + 4)):
+        out = np.empty(cap, dtype=np.uint8)
+        nbytes = L.pcc_rans_encode_with_indexes(ptr(symbols), ptr(indexes), n, ptr(cdf), cdf.shape[1],
+                                                ptr(cdf_length), ptr(offset), ptr(out), cap)
+        if nbytes >= 0:
+            return out[:nbytes].tobytes()
+    check(nbytes)
 
 
 def _rans_decode(data, indexes, cdf, cdf_length, offset):

@@ -1,0 +1,58 @@
+"""The C-ABI library loads without a GPU and exports exactly what include/pcc_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pcc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(pcc):
+    from pcc_amd import _lib
+    L = pcc.lib()
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in pcc_hip.h but not exported by libpcc_hip.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert sorted(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ set(names)
+
+
+def test_no_torch_types_in_header():
+    text = open(os.path.join(ROOT, "include", "pcc_hip.h")).read()
+    assert 'extern "C"' in text
+    code = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # signatures only, comments stripped
+    assert "torch" not in code.lower() and "at::" not in code and "Tensor" not in code
+    assert "#include <stdint.h>" in code and code.count("#include") == 1
+
+
+def test_host_entry_points_without_gpu(pcc):
+    L = pcc.lib()
+    assert L.pcc_version() >= 1
+    assert L.pcc_hash_capacity(1000) == 2048 and L.pcc_hash_capacity(3) == 1024
+    assert L.pcc_scan_scratch_elems(5000) >= 2 * 5000
+    assert L.pcc_conv_packed_elems(27, 128, 3) == 27 * 128 * 32
+    assert L.pcc_topk_state_elems(2) >= 2 * 259
+    # error path: message available, no exception across the ABI
+    pmf = np.array([-1.0, 2.0], dtype=np.float32)
+    cdf = np.zeros(3, dtype=np.int32)
+    rc = L.pcc_pmf_to_quantized_cdf(pmf.ctypes.data, 2, 16, cdf.ctypes.data)
+    assert rc < 0 and b"pmf" in L.pcc_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "learned-compression-of-point-cloud-geometry-and-attributes_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src or f.endswith(".md"), f

@@ -1,0 +1,100 @@
+"""The CPU oracle against the committed golden vectors (tests/golden/, made by make_golden.py).
+
+Integer / byte facts must match exactly.  Facts that pass through fp32 sgemm (stream bytes, bpp,
+PSNR) are compared exactly when the host reproduces the generating machine's summation order and
+within a tolerance otherwise (a different CPU may flip a few symbols on rounding boundaries).
+"""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import rans as crans
+from oracle.codec import count_bits
+from oracle.entropy import GaussianConditional
+from oracle.metrics import pc_metrics
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(GOLD, name + ".json")) as f:
+        return json.load(f)
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def test_integer_kats():
+    g = load("integer_kats")
+    c = np.asarray(g["coords"], dtype=np.int32)
+    assert oc.kernel_map(c, c, 3, 1).tolist() == g["kernel_map_k3_s1"]
+    assert oc.stride_map(c, 1).tolist() == g["stride_map_ts1"]
+    c2 = c * np.array([1, 2, 2, 2])
+    assert oc.children(c2, 2, 2).tolist() == g["children_k2_ts2"]
+    assert oc.children(c2, 2, 3).shape[0] == g["children_k3_ts2_count"]
+    assert oc.sort_order(c[::-1]).tolist() == g["sort_order"]
+
+
+def test_entropy_kats():
+    g = load("entropy_kats")
+    gc = GaussianConditional()
+    gc.update()
+    assert gc.cdf_length.tolist() == g["gc_cdf_length"] and gc.offset.tolist() == g["gc_offset"]
+    assert sha(np.ascontiguousarray(gc.cdf).tobytes()) == g["gc_cdf_sha256"]
+    for key, want in g["pmf_cases"].items():
+        assert crans.pmf_to_quantized_cdf(json.loads(key)).tolist() == want
+    rng = np.random.default_rng(g["rans_seed"])
+    n = g["rans_n"]
+    idx = rng.integers(0, 40, n).astype(np.int32)
+    sym = np.rint(rng.normal(0, 1, n) * gc.scale_table.numpy()[idx]).astype(np.int32)
+    sym[::211] = rng.integers(-5000, 5000, sym[::211].shape)
+    data = crans.encode_with_indexes(sym, idx, gc.cdf, gc.cdf_length, gc.offset)
+    assert len(data) == g["rans_bytes"] and sha(data) == g["rans_sha256"]
+    assert (crans.decode_with_indexes(data, idx, gc.cdf, gc.cdf_length, gc.offset) == sym).all()
+
+
+def test_product_host_coder_matches_golden_stream(pcc):
+    """libpcc_hip.so's host rANS (no GPU needed) must emit the golden bytes too."""
+    from pcc_amd import entropy as pe
+    g = load("entropy_kats")
+    gc = GaussianConditional()
+    gc.update()
+    rng = np.random.default_rng(g["rans_seed"])
+    n = g["rans_n"]
+    idx = rng.integers(0, 40, n).astype(np.int32)
+    sym = np.rint(rng.normal(0, 1, n) * gc.scale_table.numpy()[idx]).astype(np.int32)
+    sym[::211] = rng.integers(-5000, 5000, sym[::211].shape)
+    data = pe._rans_encode(sym, idx, gc.cdf, gc.cdf_length, gc.offset)
+    assert sha(data) == g["rans_sha256"]
+    assert (pe._rans_decode(data, idx, gc.cdf, gc.cdf_length, gc.offset) == sym).all()
+
+
+def test_config1_oracle_end_to_end(pcc, seeded_state_dict, oracle_codec):
+    g = load("config1_oracle")
+    assert sha(b"".join(v.numpy().tobytes() for _, v in sorted(seeded_state_dict.items()))) == g["state_dict_sha256"]
+    syn = pcc.synthetic
+    torch.set_num_threads(1)
+    pts = syn.sphere_shell(**syn.CONFIG1)
+    assert pts.shape[0] == g["n_points"]
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    strings, shape, k, coords = oracle_codec.compress(pts, qc, qf)
+    assert k == g["k"] and shape == g["shape"]                                    # transforms.py:89-127 order
+    assert sha(np.ascontiguousarray(coords[oc.sort_order(coords)]).tobytes()) == g["latent_coords_sha256"]
+    rec = oracle_codec.decompress(coords, strings, shape, k)
+    assert rec.shape == (g["n_points"], 6)
+    met = pc_metrics(pts, rec)
+    exact = sha(strings[0][0]) == g["sha256_y"] and sha(strings[1][0]) == g["sha256_z"]
+    if exact:
+        order = np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))
+        assert sha(np.ascontiguousarray(rec[order, :3].astype(np.int32)).tobytes()) == g["recon_geometry_sha256"]
+        assert abs(met["sym_psnr_mse"] - g["d1_psnr"]) < 1e-9 and abs(met["sym_y_psnr"] - g["y_psnr"]) < 1e-6
+    else:   # other CPU / BLAS summation order
+        assert abs(len(strings[0][0]) - g["len_y"]) <= 0.01 * g["len_y"] + 8
+        assert abs(count_bits(strings) / pts.shape[0] - g["bpp"]) <= 5e-3 * g["bpp"]
+        assert abs(met["sym_psnr_mse"] - g["d1_psnr"]) < 0.05 and abs(met["sym_y_psnr"] - g["y_psnr"]) < 0.05
