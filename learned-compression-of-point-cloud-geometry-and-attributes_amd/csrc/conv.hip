@@ -14,6 +14,8 @@
 // pcc_kernel_map): adding an all-zero product is exact, so skipping does not change results.
 //
 // Roofline: MFMA fp32 (157 TFLOP/s); algorithmic FLOPs per launch = 2 * pairs * cin * cout.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pcc {
@@ -34,6 +36,7 @@ struct ConvArgs {
     const float* residual;  // [n_out, cout] or null
     int64_t n_in, n_out;
     int cin, cout, coutp, K, act;
+    int debug;   // development ablations (PCC_CONV_DEBUG): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -70,7 +73,7 @@ constexpr int A_ELEMS = BM * A_LD;   // per buffer
 template <int BN>
 constexpr int conv_lds_bytes() { return 2 * (A_ELEMS + 8 * BN * 4) * (int)sizeof(float); }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
@@ -132,25 +135,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     f32x4 areg[4];
     bool amask[4];
     f32x4 wreg[W_LOADS];
-
-    auto load_idx = [&](int k, int (&dst)[4]) {
+    // per-thread constants of the tile: which of my 4 gather rows exist, and where their nbr rows start.
+    // Index loads are kept raw (no select on the loaded value) so that hipcc does not wait for them
+    // at the point of issue; validity is folded in when the index is consumed.
+    bool rvalid[4];
+    const int32_t* nbr_row[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            // branch-free: read a clamped row, then mask (conditional loads make hipcc wait for the
-            // data at the join, which serialises the gather behind the MFMAs)
-            const int64_t row = row0 + grow + 32 * i;
-            const int64_t rs = row < a.n_out ? row : a.n_out - 1;
-            const int v = a.nbr ? a.nbr[rs * K + k] : (int)rs;
-            dst[i] = row < a.n_out ? v : -1;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t pos = row0 + grow + 32 * i;
+        rvalid[i] = pos < a.n_out;
+        const int64_t ps = rvalid[i] ? pos : a.n_out - 1;
+        nbr_row[i] = HAS_NBR ? a.nbr + ps * K : nullptr;
+        idx_cur[i] = idx_nxt[i] = (int)ps;          // identity map when nbr == NULL (kernel_size 1)
+    }
+
+    auto load_idx = [&](int k, int (&dst)[4]) {     // unconditional loads: see the note above
+        if (HAS_NBR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dst[i] = nbr_row[i][k];
         }
     };
     auto load_step = [&](int k, int c, const int (&idx)[4]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             // absent neighbours read row 0 (always valid, L1-resident) and are zeroed in store_step
-            const int64_t src = idx[i] < 0 ? 0 : idx[i];
+            const bool ok = rvalid[i] && idx[i] >= 0;
+            const int64_t src = ok ? idx[i] : 0;
             areg[i] = *reinterpret_cast<const f32x4*>(a.fin + src * a.cin + c * 32 + gchunk * 4);
-            amask[i] = idx[i] >= 0;
+            amask[i] = ok;
         }
         const float* wbase = a.wp + (((int64_t)k * (a.cin / 4) + c * 8) * a.coutp + nt * BN) * 4;
 #pragma unroll
@@ -171,14 +183,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<f32x4*>(Wb + (t + 256 * j) * 4) = wreg[j];
     };
-    auto compute = [&](int buf, int k) {
+    // Fast path (every 32-row tile of the wave has offset k -- the common case once rows are ordered by
+    // mask): straight-line code, fragments of sub-block kk+1 are fetched from LDS while the 16 MFMAs of
+    // sub-block kk run, so the MFMA stream never waits on an LDS round trip inside a step.
+    auto compute_full = [&](int buf) {
+        const float* Ab = As + buf * A_ELEMS + (wrow + r) * A_LD + 4 * h;
+        const float* Wb = Ws + buf * W_ELEMS + (h * BN + wcol + r) * 4;
+        f32x4 av[2][MT], bv[2][NT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[0][n] = *reinterpret_cast<const f32x4*>(Wb + 32 * n * 4);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cb = kk & 1, nb = cb ^ 1;
+            if (kk + 1 < 4) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    av[nb][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD + 8 * (kk + 1));
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    bv[nb][n] = *reinterpret_cast<const f32x4*>(Wb + (2 * (kk + 1) * BN + 32 * n) * 4);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
+        }
+    };
+    // Slow path: some 32-row tile of the wave lacks offset k (mask boundaries, ragged last tile).
+    auto compute_partial = [&](int buf, int k) {
         const float* Ab = As + buf * A_ELEMS;
         const float* Wb = Ws + buf * W_ELEMS;
-        bool live[MT];
-        bool any = false;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) { live[m] = (mmask[m] >> k) & 1u; any |= live[m]; }
-        if (!any) return;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 bv[NT];
@@ -187,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 bv[n] = *reinterpret_cast<const f32x4*>(Wb + ((2 * kk + h) * BN + wcol + 32 * n + r) * 4);
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                if (!live[m]) continue;      // wave-uniform: no row of this 32-row tile has offset k
+                if (!((mmask[m] >> k) & 1u)) continue;      // wave-uniform
                 const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (wrow + 32 * m + r) * A_LD + 8 * kk + 4 * h);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
@@ -197,8 +236,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             }
         }
     };
+    uint32_t mall = mmask[0], many = mmask[0];
+#pragma unroll
+    for (int m = 1; m < MT; ++m) { mall &= mmask[m]; many |= mmask[m]; }
+    auto compute = [&](int buf, int k) {
+        if ((mall >> k) & 1u) compute_full(buf);
+        else if ((many >> k) & 1u) compute_partial(buf, k);
+    };
 
     if (tmask != 0u) {
+        // Step sequence: live offsets k ascending, CCH channel chunks each.  Every global load in the loop
+        // is unconditional and lands directly in loop-carried registers: a load under a branch (or a
+        // select on a freshly loaded value) makes hipcc wait for it at the join, which would put the
+        // L2 / HBM round trip of the neighbour indices in front of the MFMA stream.
         uint32_t rem = tmask;
         int k = __builtin_ctz(rem);
         rem &= rem - 1u;
@@ -206,29 +256,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         load_idx(k, idx_cur);
         load_step(k, 0, idx_cur);
         store_step(0);
-        if (knext >= 0) load_idx(knext, idx_nxt);
+        load_idx(knext >= 0 ? knext : k, idx_nxt);
         __syncthreads();
         int c = 0, cur = 0;
         while (true) {
             int nk = k, nc = c + 1;
             if (nc == CCH) { nc = 0; nk = knext; }
             const bool has_next = nk >= 0;
-            if (has_next) {
-                if (nc == 0) load_step(nk, 0, idx_nxt);
-                else load_step(nk, nc, idx_cur);
-            }
-            compute(cur, k);
-            if (has_next) store_step(cur ^ 1);
-            __syncthreads();
-            if (!has_next) break;
-            if (nc == 0) {
-                k = nk;
+            const bool advance = (nc == 0);
+            if (advance) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) idx_cur[i] = idx_nxt[i];
-                rem &= rem - 1u;
-                knext = rem ? __builtin_ctz(rem) : -1;
-                if (knext >= 0) load_idx(knext, idx_nxt);
+                for (int i = 0; i < 4; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
             }
+            if (has_next && !(a.debug & 1)) load_step(nk, nc, idx_cur);
+            // indices of the offset after next: issued a full step (or more) before their first use
+            uint32_t rem2 = rem;
+            int kn2 = knext;
+            if (advance) { rem2 &= rem2 - 1u; kn2 = rem2 ? __builtin_ctz(rem2) : -1; }
+            load_idx(kn2 >= 0 ? kn2 : k, idx_nxt);
+            if (!(a.debug & 8)) compute(cur, k);
+            if (has_next && !(a.debug & 2)) store_step(cur ^ 1);
+            if (!(a.debug & 4)) __syncthreads();
+            if (!has_next) break;
+            if (advance) { k = nk; rem = rem2; knext = kn2; }
             c = nc;
             cur ^= 1;
         }
@@ -295,11 +345,13 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
-static int launch_mfma(const ConvArgs& a, hipStream_t st) {
+template <int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
+static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<BN, WAVES_M, WAVES_N>;
-    constexpr int lds = conv_lds_bytes<BN>();
+    auto kern = conv_mfma_kernel<BN, WAVES_M, WAVES_N, HAS_NBR>;
+    static int extra_lds = -1;      // development knob: PCC_CONV_EXTRA_LDS=<bytes> lowers workgroups per CU
+    if (extra_lds < 0) { const char* e = getenv("PCC_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
+    const int lds = conv_lds_bytes<BN>() + extra_lds;
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -310,6 +362,11 @@ static int launch_mfma(const ConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+static int launch_mfma(const ConvArgs& a, hipStream_t st) {
+    return a.nbr ? launch_mfma_impl<BN, WAVES_M, WAVES_N, true>(a, st) : launch_mfma_impl<BN, WAVES_M, WAVES_N, false>(a, st);
 }
 
 template <int CIN>
@@ -355,6 +412,7 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
     a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout;
     a.film = film; a.residual = residual; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout;
     a.coutp = round_up32(cout); a.K = K; a.act = act;
+    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("PCC_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     hipStream_t st = as_stream(stream);
     if (cin % 32 == 0) {
         PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd: MFMA path (cin=%d) needs packed weights", cin);
