@@ -49,15 +49,23 @@ def cpu_baseline(state_dict, sample):
     grid, radius, hw = sample.split(",")
     pts = pcc_amd.synthetic.sphere_shell(int(grid), float(radius), float(hw))
     qc, qf = pcc_amd.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
-    threads = os.cpu_count() or 1
+    # threads actually available to this process (a 1-GPU box gives a 16-core share), never more
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = max(1, min(avail, 16))
     torch.set_num_threads(threads)
+    print(f"[bench] cpu_baseline: oracle on N={pts.shape[0]} points with {threads} threads ...", file=sys.stderr, flush=True)
     codec = Codec(state_dict)
     codec.update()
     t0 = time.time()
     strings, shape, k, coords = codec.compress(pts, qc, qf)
     t1 = time.time()
+    print(f"[bench] cpu_baseline: encode {t1 - t0:.1f} s", file=sys.stderr, flush=True)
     codec.decompress(coords, strings, shape, k)
     t2 = time.time()
+    print(f"[bench] cpu_baseline: decode {t2 - t1:.1f} s", file=sys.stderr, flush=True)
     n = pts.shape[0]
     return {"value": n / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
             "sample": f"one {grid}^3 sphere-shell frame, N={n} points, q=(0.5,0.5), same weights; "

@@ -65,7 +65,7 @@ inline void enc_sym_init(EncSym& s, uint32_t start, uint32_t freq) {
 
 struct Writer {
     uint32_t* ptr;   // grows downwards
-    uint32_t* base;  // lowest writable word
+    uint32_t* base;  // lowest writable word (one spare word below it is always writable)
     bool overflow = false;
     inline void emit(uint32_t v) {
         if (ptr > base) *--ptr = v;
@@ -74,7 +74,12 @@ struct Writer {
 };
 
 inline void put_sym(uint64_t& x, Writer& w, const EncSym& s) {
-    if (x >= s.x_max) { w.emit((uint32_t)x); x >>= 32; }
+    // branch-free renormalisation (taken for about every other symbol -> unpredictable as a branch):
+    // the word is always stored below ptr, and kept only if needed
+    const bool need = x >= s.x_max;
+    if (w.ptr <= w.base) { if (need) w.overflow = true; }
+    else { w.ptr[-1] = (uint32_t)x; w.ptr -= need ? 1 : 0; }
+    x = need ? (x >> 32) : x;
     const uint64_t q = mul_hi(x, s.rcp_freq) >> s.rcp_shift;
     x = x + s.bias + q * s.cmpl_freq;
 }
@@ -159,25 +164,36 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
         if (indexes[i] < 0) { pcc::set_error("pcc_rans_decode_with_indexes: negative table index"); return PCC_ERR_DATA; }
         if (indexes[i] > max_ix) max_ix = indexes[i];
     }
-    // per-table decode state packed back to back (cache-friendly: the caller's [n_tables, stride]
-    // int32 matrix is ~800 KB, its used prefix a few tens of KB) + a bucket table:
-    // lut[t][b] = symbol whose interval contains slot b << 8
+    // Per-table decode state packed back to back (the caller's [n_tables, stride] int32 matrix is
+    // ~800 KB, its used prefix a few tens of KB):
+    //   lut[b]  = symbol whose interval contains slot b << 8, bit 15 set when the whole bucket
+    //             [b << 8, (b + 1) << 8) lies inside that symbol (no search needed);
+    //   sf[s]   = start | freq << 16   (one load instead of cdf[s], cdf[s + 1]);
+    //   cdf[]   = the row itself, for the short forward scan of impure buckets.
     constexpr int kBuckets = 256, kShift = kPrecision - 8;
+    struct DecTable { const uint32_t* cdf; const uint32_t* sf; const uint16_t* lut; int32_t maxv; int32_t offset; };
     std::vector<uint16_t> lut((size_t)(max_ix + 1) * kBuckets);
     std::vector<int64_t> row_off((size_t)max_ix + 2, 0);
     for (int32_t t = 0; t <= max_ix; ++t) row_off[(size_t)t + 1] = row_off[(size_t)t] + cdf_sizes[t];
     std::vector<uint32_t> packed((size_t)row_off[(size_t)max_ix + 1] + 1, 0xFFFFFFFFu);   // + sentinel
+    std::vector<uint32_t> sfv((size_t)row_off[(size_t)max_ix + 1] + 1, 0u);
+    std::vector<DecTable> tabs((size_t)max_ix + 1);
     for (int32_t t = 0; t <= max_ix; ++t) {
         const int32_t* cdf = cdfs + (int64_t)t * cdf_stride;
         uint32_t* row = packed.data() + row_off[(size_t)t];
+        uint32_t* sf = sfv.data() + row_off[(size_t)t];
+        if (cdf_sizes[t] > 32768) { pcc::set_error("pcc_rans_decode_with_indexes: table %d too long", t); return PCC_ERR_ARG; }
         for (int32_t j = 0; j < cdf_sizes[t]; ++j) row[j] = (uint32_t)cdf[j];
         const int32_t nsym = cdf_sizes[t] - 1;
-        int32_t s = 0;
+        for (int32_t j = 0; j < nsym; ++j) sf[j] = (row[j] & 0xFFFFu) | ((row[j + 1] - row[j]) << 16);
+        int32_t sidx = 0;
         for (int b = 0; b < kBuckets; ++b) {
             const uint32_t slot = (uint32_t)b << kShift;
-            while (s + 1 < nsym && row[s + 1] <= slot) ++s;
-            lut[(size_t)t * kBuckets + b] = (uint16_t)s;
+            while (sidx + 1 < nsym && row[sidx + 1] <= slot) ++sidx;
+            const bool pure = row[sidx + 1] >= slot + (1u << kShift);
+            lut[(size_t)t * kBuckets + b] = (uint16_t)(sidx | (pure ? 0x8000 : 0));
         }
+        tabs[(size_t)t] = DecTable{row, sf, lut.data() + (size_t)t * kBuckets, cdf_sizes[t] - 2, offsets[t]};
     }
     const int64_t nwords = nbytes / 4;
     std::vector<uint32_t> words((size_t)nwords + 4, 0u);   // zero padding: reads past the end yield 0
@@ -186,18 +202,27 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
     const uint32_t* const end = p + nwords;
     uint64_t x = (uint64_t)p[0] | ((uint64_t)p[1] << 32);
     p += 2;
-    auto refill = [&]() { if (x < kRansL) { const uint32_t wv = (p < end) ? *p : 0u; ++p; x = (x << 32) | wv; } };
+    // branch-free renormalisation: the refill happens for roughly every other symbol, so a branch here
+    // mispredicts constantly; words[] is zero-padded, and p is clamped so it never leaves the buffer
+    auto refill = [&]() {
+        const bool need = x < kRansL;
+        const uint64_t xn = (x << 32) | *p;
+        x = need ? xn : x;
+        p += (need && p < end) ? 1 : 0;
+    };
     auto get_bits = [&]() -> uint32_t { const uint32_t v = (uint32_t)(x & kBypassMax); x >>= kBypassBits; refill(); return v; };
     for (int64_t i = 0; i < n; ++i) {
-        const int32_t ix = indexes[i];
-        const uint32_t* cdf = packed.data() + row_off[(size_t)ix];
-        const int32_t size = (int32_t)(row_off[(size_t)ix + 1] - row_off[(size_t)ix]);
-        const int32_t maxv = size - 2;
+        const DecTable& tb = tabs[(size_t)indexes[i]];
+        const int32_t maxv = tb.maxv;
         const uint32_t cf = (uint32_t)(x & 0xFFFFu);
-        int32_t s = lut[(size_t)ix * kBuckets + (cf >> kShift)];
-        // == (first j with cdf[j] > cf) - 1; the row ends with 2^16 > cf, so the scan stops in range
-        while (cdf[s + 1] <= cf) ++s;
-        x = (uint64_t)(cdf[s + 1] - cdf[s]) * (x >> kPrecision) + cf - cdf[s];
+        const uint32_t e = tb.lut[cf >> kShift];
+        int32_t s = (int32_t)(e & 0x7FFFu);
+        if (!(e & 0x8000u)) {
+            // == (first j with cdf[j] > cf) - 1; the row ends with 2^16 > cf, so the scan stops in range
+            while (tb.cdf[s + 1] <= cf) ++s;
+        }
+        const uint32_t sfe = tb.sf[s];
+        x = (uint64_t)(sfe >> 16) * (x >> kPrecision) + cf - (sfe & 0xFFFFu);
         refill();
         int32_t value = s;
         if (value == maxv) {
@@ -209,7 +234,7 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
             value = (int32_t)(raw >> 1);
             value = (raw & 1u) ? -value - 1 : value + maxv;
         }
-        out_symbols[i] = value + offsets[ix];
+        out_symbols[i] = value + tb.offset;
     }
     return PCC_OK;
 }

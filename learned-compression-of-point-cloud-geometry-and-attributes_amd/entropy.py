@@ -46,6 +46,38 @@ def _pmf_to_cdf(pmf, tail, pmf_length, max_length):
     return cdf
 
 
+# Pinned staging buffers for the symbol / index planes (the only per-frame host traffic of the
+# path): page-locked copies run at PCIe rate instead of through a pageable bounce buffer.
+_PINNED = {}
+
+
+def _pinned(key, numel, dtype):
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < numel or buf.dtype != dtype:
+        buf = torch.empty(max(numel, 1), dtype=dtype, pin_memory=True)
+        _PINNED[key] = buf
+    return buf[:numel]
+
+
+def _to_host(t, key):
+    """Device tensor -> numpy view of a pinned host buffer (valid until the next call with ``key``)."""
+    t = t.contiguous()
+    buf = _pinned(key, t.numel(), t.dtype)
+    buf.copy_(t.reshape(-1), non_blocking=True)
+    torch.cuda.current_stream(t.device).synchronize()
+    return buf.numpy().reshape(t.shape)
+
+
+def _to_device(arr, device, key):
+    """numpy array -> device tensor through a pinned staging buffer."""
+    src = torch.from_numpy(np.ascontiguousarray(arr))
+    buf = _pinned(key, src.numel(), src.dtype)
+    buf.copy_(src.reshape(-1))
+    out = buf.to(device, non_blocking=True).reshape(src.shape)
+    torch.cuda.current_stream(out.device).synchronize()    # the staging buffer is reused by the next call
+    return out
+
+
 def _rans_encode(symbols, indexes, cdf, cdf_length, offset):
     """symbols / indexes: host int32 arrays (flattened channel-major)."""
     L = _lib.lib()
@@ -225,7 +257,7 @@ class EntropyBottleneck(_EntropyModelBase):
         cdf, cdf_len, off = self.tables()
         c, n = sym.shape
         idx = np.repeat(np.arange(c, dtype=np.int32), n)
-        return [_rans_encode(sym.cpu().numpy(), idx, cdf, cdf_len, off)], zhat
+        return [_rans_encode(_to_host(sym, "eb_sym"), idx, cdf, cdf_len, off)], zhat
 
     def compress(self, x):
         strings, _ = self.compress_features(x[0].t().contiguous())
@@ -307,7 +339,7 @@ class GaussianConditional(_EntropyModelBase):
             p = perm.long()
             sym, idx = sym.index_select(1, p), idx.index_select(1, p)
         cdf, cdf_len, off = self.tables()
-        both = torch.stack([sym, idx]).cpu().numpy()
+        both = _to_host(torch.stack([sym, idx]), "gc_sym_idx")
         return [_rans_encode(both[0], both[1], cdf, cdf_len, off)]
 
     def decompress_features(self, strings, params, c):
@@ -316,7 +348,7 @@ class GaussianConditional(_EntropyModelBase):
         dev = params.device
         idx = self.indexes_for(params, c)
         cdf, cdf_len, off = self.tables()
-        sym = torch.from_numpy(_rans_decode(strings[0], idx.cpu().numpy(), cdf, cdf_len, off).reshape(c, n)).to(dev)
+        sym = _to_device(_rans_decode(strings[0], _to_host(idx, "gc_idx"), cdf, cdf_len, off).reshape(c, n), dev, "gc_sym_up")
         yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
         check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
         return yhat
