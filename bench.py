@@ -187,8 +187,18 @@ def main():
     if dom_name:
         d = classes[dom_name]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
+        # same command, reduced by tools/pmc_traffic.py and committed under profiles/
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic_conv_mfma128.json")
+        if dom_name == "conv_mfma<128>" and args.workload == "config2" and os.path.exists(tfile):
+            with open(tfile) as f:
+                traffic = json.load(f)["traffic_bytes_per_launch"]
+            traffic_src = "profiles/r01_traffic_conv_mfma128.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+                    "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
+                    "algorithmic_gather_bytes_per_launch": d["gather_bytes"] / d["launches"],
                     "launches_per_step": d["launches"] / args.steps,
                     "avg_launch_ms": d["ms"] / d["launches"],
                     "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

@@ -161,13 +161,16 @@ __global__ __launch_bounds__(256) void order_keys_kernel(const uint32_t* __restr
                                                          int32_t* __restrict__ iota) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    uint64_t key = row_mask[i] & 0x7FFFFFFu;
+    // heaviest rows first (27 - popcount in the bits above the mask): tiles are dispatched in key
+    // order, so the expensive ones start early and the tail of a launch consists of cheap tiles
+    const uint32_t m = row_mask[i] & 0x7FFFFFFu;
+    uint64_t key = ((uint64_t)(27 - __popc(m)) << 27) | m;
     if (block_log2 >= 0) {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
         const uint64_t bx = (uint64_t)(((c.y / ts) + 512) >> block_log2) & 0x3FF;
         const uint64_t by = (uint64_t)(((c.z / ts) + 512) >> block_log2) & 0x3FF;
         const uint64_t bz = (uint64_t)(((c.w / ts) + 512) >> block_log2) & 0x3FF;
-        key |= ((((uint64_t)(c.x & 0x3F) << 30) | (bx << 20) | (by << 10) | bz) << 27);
+        key |= ((((uint64_t)(c.x & 0x3) << 30) | (bx << 20) | (by << 10) | bz) << 32);
     }
     keys[i] = key;
     iota[i] = (int32_t)i;
@@ -243,7 +246,7 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
     hipLaunchKernelGGL(order_keys_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, coords, n, block_log2,
                        tensor_stride, keys_in, iota);
-    const int end_bit = block_log2 >= 0 ? 64 : 27;
+    const int end_bit = block_log2 >= 0 ? 64 : 32;
     PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(p, temp, keys_in, keys_out, iota, order, (int)n, 0, end_bit, st));
     hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
                        nbr_sorted, group_mask32);

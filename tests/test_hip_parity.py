@@ -153,8 +153,10 @@ def test_kernel_map(pcc, case):
         sm = want_mask[order]
         for g in range(gm.shape[0]):
             assert int(gm[g]) == int(np.bitwise_or.reduce(sm[g * 32:(g + 1) * 32]))
-        if blk < 0:
-            assert (np.diff(sm) >= 0).all()          # sorted by mask
+        if blk < 0:                                 # sorted by (popcount descending, mask ascending)
+            pc = np.array([bin(int(v)).count("1") for v in sm])
+            key = ((27 - pc).astype(np.int64) << 27) | sm
+            assert (np.diff(key) >= 0).all()
 
 
 CONV_SHAPES = [

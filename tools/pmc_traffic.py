@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as
+MI355X_MICROARCH.md prescribes) into the per-launch HBM traffic of the dominant kernel.
+
+usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <kernel substring> <out.json>
+
+gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE is in KB and reports half the bytes of
+wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE is in KB and exact for streaming stores.
+"""
+import csv, json, sys
+
+def per_dispatch(path, counter, substr):
+    out = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and substr in r["Kernel_Name"]:
+            out[r["Dispatch_Id"]] = out.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
+    return out
+
+fetch = per_dispatch(sys.argv[1], "FETCH_SIZE", sys.argv[3])
+write = per_dispatch(sys.argv[2], "WRITE_SIZE", sys.argv[3])
+n = min(len(fetch), len(write))
+assert n > 0, "no matching dispatches"
+fb = sum(fetch.values()) / len(fetch) * 1024 * 2
+wb = sum(write.values()) / len(write) * 1024
+json.dump({"kernel": sys.argv[3], "launches_fetch_pass": len(fetch), "launches_write_pass": len(write),
+           "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "traffic_bytes_per_launch": fb + wb,
+           "note": "FETCH_SIZE x2 (gfx950 wide-read correction), KB -> bytes; averages over all launches of the kernel in one bench step"},
+          open(sys.argv[4], "w"), indent=1)
+print(open(sys.argv[4]).read())
