@@ -76,3 +76,35 @@ def all_gather_bitstreams(payload, device, group=None):
     dist.all_gather_into_tensor(out, buf, group=group)
     host = out.cpu().numpy()
     return [host[r * mx: r * mx + lens_host[r]].tobytes() for r in range(world)]
+
+
+# ---------------------------------------------------------------------------------------------
+# spatial-block mode: every cube is an independent unit coded by the unmodified single-GPU path
+# ---------------------------------------------------------------------------------------------
+def compress_blocks(model, x, q_feats, block, rank=0, world=1):
+    """Code the cubes of edge ``block`` assigned to ``rank``.
+
+    x: float [N, 6] device tensor (xyz voxel coordinates + rgb), q_feats: [N, 2] (q_g, q_a).
+    Coordinates stay absolute (stride alignment is the whole-frame one).  Returns
+    (block ids [M,3], assignment, units) with units = [(block index, strings, shape, k, coords8)].
+    """
+    from .sparse import SparseTensor
+    xyz = x[:, :3].detach().cpu().numpy()
+    ids, rows = split_blocks(xyz, block)
+    parts = assign_blocks([len(r) for r in rows], world)
+    units = []
+    for b in parts[rank]:
+        sel = torch.from_numpy(rows[b]).to(x.device)
+        xb = x.index_select(0, sel)
+        qc = torch.cat([torch.zeros((xb.shape[0], 1), device=x.device), xb[:, :3]], dim=1)
+        Q = SparseTensor(coordinates=qc, features=q_feats.index_select(0, sel), device=x.device)
+        strings, shape, k, coords = model.compress(xb, Q)
+        units.append((b, strings, shape, k, coords))
+    return ids, parts, units
+
+
+def decompress_blocks(model, units):
+    """Decode units produced by ``compress_blocks`` -> float [N_hat, 6] (concatenated cubes)."""
+    out = [model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+           for _, strings, shape, k, coords in units]
+    return torch.cat(out, dim=0)

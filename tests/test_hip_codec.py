@@ -136,3 +136,34 @@ def test_missing_update_fails_loudly(pcc):
 def test_cpu_tensors_are_rejected(pcc):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         pcc.CoordMap(torch.zeros((4, 4), dtype=torch.int32), 1)
+
+
+def test_block_partition_mode_vs_oracle_with_same_partition(pcc, model, oracle_codec):
+    """SURVEY §8e option 2: cubes as independent units.  Parity target = the oracle run on the SAME
+    partition (block coding changes the numbers relative to whole-frame coding)."""
+    from pcc_amd import parallel as par
+    cfg = dict(grid=64, radius=27.0, half_width=0.6)
+    pts, qc, qf = _inputs(pcc, cfg)
+    x = torch.from_numpy(pts).to(DEV)
+    ids, parts, units0 = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=0, world=2)
+    _, _, units1 = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=1, world=2)
+    assert sorted(parts[0] + parts[1]) == list(range(len(ids))) and len(ids) == 8
+    units = sorted(units0 + units1, key=lambda u: u[0])
+    rec = par.decompress_blocks(model, units).cpu().numpy()
+    # oracle on the same cubes
+    _, rows = par.split_blocks(pts, 32)
+    o_bits, o_rec = 0, []
+    bits = 0
+    for (b, strings, shape, k, coords), r in zip(units, rows):
+        pb = pts[r]
+        qcb, qfb = pcc.synthetic.uniform_qmap(pb[:, :3], 0.5, 0.5)
+        o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pb, qcb, qfb)
+        assert shape == o_shape and k == o_k and coords.shape[0] == o_coords.shape[0]
+        o_bits += count_bits(o_strings)
+        bits += count_bits(strings)
+        o_rec.append(oracle_codec.decompress(o_coords, o_strings, o_shape, o_k))
+    o_rec = np.concatenate(o_rec, axis=0)
+    assert rec.shape == o_rec.shape == (pts.shape[0], 6)
+    assert abs(bits - o_bits) <= 3e-3 * o_bits + 64
+    m, om = pc_metrics(pts, rec), pc_metrics(pts, o_rec)
+    assert abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]) <= 2e-2 and abs(m["sym_y_psnr"] - om["sym_y_psnr"]) <= 2e-2
