@@ -1,20 +1,22 @@
 // Sparse convolution forward for gfx950.
 //
-// Output-stationary implicit GEMM: a workgroup owns 128 output rows x BN output channels and
+// Output-stationary implicit GEMM: a workgroup owns BM (64) output rows x BN output channels and
 // walks the kernel offsets k (in ascending order) and the input channels in chunks of 32.  For each
-// (k, chunk) it gathers the 128 neighbour rows' 128-byte slices into LDS (zero for absent
-// neighbours), stages the matching 32 x BN weight slab, and feeds fp32 MFMA
+// (k, chunk) it gathers the neighbour rows' 128-byte slices straight into LDS by LDS-DMA (a line
+// of zeros for absent neighbours), stages the matching 32 x BN weight slab, and feeds fp32 MFMA
 // (v_mfma_f32_32x32x2_f32; exact fp32, SURVEY.md §7 "fp32 parity budget").  Accumulation order per
 // output element is fixed (k ascending, channel ascending inside the MFMA chain), so a result
 // depends only on the element's own neighbourhood — never on row order, tile placement or
 // arrival order.  That is what lets encoder and decoder reproduce h_s bit-exactly
 // (the job of the reference's Sorted* shims, model/entropy_models.py:12-102).
 //
-// Offsets with no neighbour anywhere in a 64-row group are skipped (group masks from
-// pcc_kernel_map): adding an all-zero product is exact, so skipping does not change results.
+// Rows are executed in neighbour-mask order (pcc_order_rows_by_mask); offsets that no row of a 32-row
+// MFMA tile has are skipped: adding an all-zero product is exact, so skipping does not change results.
 //
 // Roofline: MFMA fp32 (157 TFLOP/s); algorithmic FLOPs per launch = 2 * pairs * cin * cout.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "common.h"
 
@@ -66,17 +68,31 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // MFMA path
 // ---------------------------------------------------------------------------------------------
-constexpr int BM = 128;
-constexpr int A_LD = 36;             // floats per LDS row: 32 + 4 pad -> conflict-free ds_read_b128
-constexpr int A_ELEMS = BM * A_LD;   // per buffer
+constexpr int A_LD_REG = 36;   // register-staged image: 32 + 4 pad floats per row -> conflict-free ds_read_b128
+constexpr int A_LD_DMA = 32;   // LDS-DMA image: unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
 
-template <int BN>
-constexpr int conv_lds_bytes() { return 2 * (A_ELEMS + 8 * BN * 4) * (int)sizeof(float); }
+template <int BM, int BN, bool DMA>
+constexpr int conv_lds_bytes() { return 2 * (BM * (DMA ? A_LD_DMA : A_LD_REG) + 8 * BN * 4) * (int)sizeof(float); }
 
-template <int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
+// one 128-B line of zeros: the gather source of absent neighbours on the LDS-DMA path
+__device__ float g_zero_line[32] = {0.0f};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+// Staging variants of the same kernel:
+//   DMA = false  global_load_dwordx4 -> VGPR -> (zero select) -> ds_write_b128, padded A image
+//   DMA = true   global_load_lds_dwordx4 straight into LDS (no staging registers, no ds_write): the
+//                A image is unpadded; each 16-B slot p of row R holds global chunk p ^ ((R >> 1) & 7),
+//                the permutation being applied on the per-lane SOURCE address (the LDS side of an
+//                LDS-DMA is lane-linear) and undone on the fragment reads.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR, bool DMA>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
+    constexpr int RPT = BM / 32;              // gather rows per thread (8 lanes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_LD = DMA ? A_LD_DMA : A_LD_REG;
+    constexpr int A_ELEMS = BM * A_LD;
     constexpr int W_ELEMS = 8 * BN * 4;
     constexpr int W_LOADS = (8 * BN) / 256;  // float4 per thread per chunk
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && NT >= 1 && W_LOADS >= 1, "bad tiling");
@@ -129,35 +145,40 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
 
-    // gather roles: 8 lanes per row (16 B each), 32 rows per pass, 4 passes
-    const int grow = t >> 3, gchunk = t & 7;
-    int idx_cur[4], idx_nxt[4];
-    f32x4 areg[4];
-    bool amask[4];
+    // gather roles: 8 lanes per row (16 B each).  Register path: rows grow + 32 i.  DMA path: one
+    // wave-instruction fills 1 KB = 8 consecutive rows, wave w issues instructions 4w .. 4w+3.
+    const int gchunk = t & 7;
+    int grow[RPT];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) grow[i] = DMA ? (wid * (BM / 4) + 8 * i + (lane >> 3)) : ((t >> 3) + 32 * i);
+    int idx_cur[RPT], idx_nxt[RPT];
+    f32x4 areg[RPT];
+    bool amask[RPT];
     f32x4 wreg[W_LOADS];
     // per-thread constants of the tile: which of my 4 gather rows exist, and where their nbr rows start.
     // Index loads are kept raw (no select on the loaded value) so that hipcc does not wait for them
     // at the point of issue; validity is folded in when the index is consumed.
-    bool rvalid[4];
-    const int32_t* nbr_row[4];
+    bool rvalid[RPT];
+    const int32_t* nbr_row[RPT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t pos = row0 + grow + 32 * i;
+    for (int i = 0; i < RPT; ++i) {
+        const int64_t pos = row0 + grow[i];
         rvalid[i] = pos < a.n_out;
         const int64_t ps = rvalid[i] ? pos : a.n_out - 1;
         nbr_row[i] = HAS_NBR ? a.nbr + ps * K : nullptr;
         idx_cur[i] = idx_nxt[i] = (int)ps;          // identity map when nbr == NULL (kernel_size 1)
     }
 
-    auto load_idx = [&](int k, int (&dst)[4]) {     // unconditional loads: see the note above
+    auto load_idx = [&](int k, int (&dst)[RPT]) {     // unconditional loads: see the note above
         if (HAS_NBR) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) dst[i] = nbr_row[i][k];
+            for (int i = 0; i < RPT; ++i) dst[i] = nbr_row[i][k];
         }
     };
-    auto load_step = [&](int k, int c, const int (&idx)[4]) {
+    // ---- register-staged path --------------------------------------------------------------------
+    auto load_step = [&](int k, int c, const int (&idx)[RPT]) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RPT; ++i) {
             // absent neighbours read row 0 (always valid, L1-resident) and are zeroed in store_step
             const bool ok = rvalid[i] && idx[i] >= 0;
             const int64_t src = ok ? idx[i] : 0;
@@ -176,22 +197,57 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         float* Ab = As + buf * A_ELEMS;
         float* Wb = Ws + buf * W_ELEMS;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < RPT; ++i) {
             const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            *reinterpret_cast<f32x4*>(Ab + (grow + 32 * i) * A_LD + gchunk * 4) = amask[i] ? areg[i] : z;
+            *reinterpret_cast<f32x4*>(Ab + grow[i] * A_LD + gchunk * 4) = amask[i] ? areg[i] : z;
         }
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<f32x4*>(Wb + (t + 256 * j) * 4) = wreg[j];
     };
-    // Fast path (every 32-row tile of the wave has offset k -- the common case once rows are ordered by
-    // mask): straight-line code, fragments of sub-block kk+1 are fetched from LDS while the 16 MFMAs of
-    // sub-block kk run, so the MFMA stream never waits on an LDS round trip inside a step.
-    auto compute_full = [&](int buf) {
-        const float* Ab = As + buf * A_ELEMS + (wrow + r) * A_LD + 4 * h;
+    // ---- LDS-DMA path ----------------------------------------------------------------------------
+    auto dma_step = [&](int k, int c, const int (&idx)[RPT], int buf) {
+        const int wbase_lds = __builtin_amdgcn_readfirstlane(wid);        // provably wave-uniform LDS bases
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const bool ok = rvalid[i] && idx[i] >= 0;
+            const int q = gchunk ^ ((grow[i] >> 1) & 7);                  // global chunk for my LDS slot
+            const float* src = ok ? (a.fin + (int64_t)idx[i] * a.cin + c * 32 + q * 4) : (g_zero_line + q * 4);
+            float* dst = As + buf * A_ELEMS + (wbase_lds * RPT + i) * 256;  // + lane * 16 B added by the hardware
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+        const float* wbase = a.wp + (((int64_t)k * (a.cin / 4) + c * 8) * a.coutp + nt * BN) * 4;
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) {
+            const int f = t + 256 * j;
+            const int g = f / BN, col = f - g * BN;
+            const float* src = wbase + ((int64_t)g * a.coutp + col) * 4;
+            float* dst = Ws + buf * W_ELEMS + (wbase_lds * 64 + 256 * j) * 4;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        }
+    };
+
+    // A-fragment addressing.  Lane (r, h) of a wave reads, for sub-block kk, the 16-B chunk 2 kk + h of
+    // row wrow + 32 m + r.  DMA image: physical slot = chunk ^ ((r >> 1) & 7), i.e. bit 0 -> h ^ (sw & 1)
+    // and bits 1-2 -> kk ^ (sw >> 1): four lane-constant offsets.
+    const int sw = (r >> 1) & 7;
+    int a_off[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        a_off[kk] = DMA ? ((((kk ^ (sw >> 1)) << 1) | (h ^ (sw & 1))) * 4) : (8 * kk + 4 * h);
+
+    // MFMA block of one step, specialised at compile time on WHICH of the wave's 32-row tiles have
+    // offset k (LIVE bit m = tile m).  Every variant is straight-line code: fragments of sub-block
+    // kk+1 are fetched from LDS while the MFMAs of sub-block kk run, so the MFMA stream never waits
+    // on an LDS round trip inside a step, also when only part of the wave's rows take the offset
+    // (tiles on a boundary between two neighbour-mask groups).
+    auto compute_live = [&](int buf, auto live_tag) {
+        constexpr unsigned LIVE = decltype(live_tag)::value;
+        const float* Ab = As + buf * A_ELEMS + (wrow + r) * A_LD;
         const float* Wb = Ws + buf * W_ELEMS + (h * BN + wcol + r) * 4;
         f32x4 av[2][MT], bv[2][NT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) av[0][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD);
+        for (int m = 0; m < MT; ++m)
+            if ((LIVE >> m) & 1u) av[0][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD + a_off[0]);
 #pragma unroll
         for (int n = 0; n < NT; ++n) bv[0][n] = *reinterpret_cast<const f32x4*>(Wb + 32 * n * 4);
 #pragma unroll
@@ -200,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             if (kk + 1 < 4) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
-                    av[nb][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD + 8 * (kk + 1));
+                    if ((LIVE >> m) & 1u) av[nb][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD + a_off[kk + 1]);
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     bv[nb][n] = *reinterpret_cast<const f32x4*>(Wb + (2 * (kk + 1) * BN + 32 * n) * 4);
@@ -211,37 +267,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
+                        if ((LIVE >> m) & 1u)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
         }
     };
-    // Slow path: some 32-row tile of the wave lacks offset k (mask boundaries, ragged last tile).
-    auto compute_partial = [&](int buf, int k) {
-        const float* Ab = As + buf * A_ELEMS;
-        const float* Wb = Ws + buf * W_ELEMS;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 bv[NT];
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                bv[n] = *reinterpret_cast<const f32x4*>(Wb + ((2 * kk + h) * BN + wcol + 32 * n + r) * 4);
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if (!((mmask[m] >> k) & 1u)) continue;      // wave-uniform
-                const f32x4 av = *reinterpret_cast<const f32x4*>(Ab + (wrow + 32 * m + r) * A_LD + 8 * kk + 4 * h);
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[n][s], acc[m][n], 0, 0, 0);
-            }
-        }
-    };
-    uint32_t mall = mmask[0], many = mmask[0];
-#pragma unroll
-    for (int m = 1; m < MT; ++m) { mall &= mmask[m]; many |= mmask[m]; }
     auto compute = [&](int buf, int k) {
-        if ((mall >> k) & 1u) compute_full(buf);
-        else if ((many >> k) & 1u) compute_partial(buf, k);
+        unsigned live = 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) live |= ((mmask[m] >> k) & 1u) << m;      // wave-uniform (SGPR)
+        if constexpr (MT == 1) {
+            if (live) compute_live(buf, std::integral_constant<unsigned, 1u>{});
+        } else {
+            static_assert(MT == 2, "live-pattern dispatch written for MT <= 2");
+            if (live == 3u) compute_live(buf, std::integral_constant<unsigned, 3u>{});
+            else if (live == 1u) compute_live(buf, std::integral_constant<unsigned, 1u>{});
+            else if (live == 2u) compute_live(buf, std::integral_constant<unsigned, 2u>{});
+        }
     };
 
     if (tmask != 0u) {
@@ -254,10 +295,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         rem &= rem - 1u;
         int knext = rem ? __builtin_ctz(rem) : -1;
         load_idx(k, idx_cur);
-        load_step(k, 0, idx_cur);
-        store_step(0);
+        if constexpr (DMA) dma_step(k, 0, idx_cur, 0);
+        else { load_step(k, 0, idx_cur); store_step(0); }
         load_idx(knext >= 0 ? knext : k, idx_nxt);
-        __syncthreads();
+        __syncthreads();        // (emits vmcnt(0): the first DMA / loads have landed)
         int c = 0, cur = 0;
         while (true) {
             int nk = k, nc = c + 1;
@@ -266,17 +307,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             const bool advance = (nc == 0);
             if (advance) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
+                for (int i = 0; i < RPT; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
             }
-            if (has_next && !(a.debug & 1)) load_step(nk, nc, idx_cur);
+            if (has_next && !(a.debug & 1)) {
+                // buffer cur^1 was last read in the previous step, which every wave has left (barrier)
+                if constexpr (DMA) dma_step(nk, nc, idx_cur, cur ^ 1);
+                else load_step(nk, nc, idx_cur);
+            }
             // indices of the offset after next: issued a full step (or more) before their first use
             uint32_t rem2 = rem;
             int kn2 = knext;
             if (advance) { rem2 &= rem2 - 1u; kn2 = rem2 ? __builtin_ctz(rem2) : -1; }
             load_idx(kn2 >= 0 ? kn2 : k, idx_nxt);
             if (!(a.debug & 8)) compute(cur, k);
-            if (has_next && !(a.debug & 2)) store_step(cur ^ 1);
-            if (!(a.debug & 4)) __syncthreads();
+            if constexpr (!DMA) { if (has_next && !(a.debug & 2)) store_step(cur ^ 1); }
+            if (!(a.debug & 4)) __syncthreads();     // vmcnt(0) + lgkmcnt(0) + barrier: next image complete
             if (!has_next) break;
             if (advance) { k = nk; rem = rem2; knext = kn2; }
             c = nc;
@@ -345,13 +390,13 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR, bool DMA>
 static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<BN, WAVES_M, WAVES_N, HAS_NBR>;
+    auto kern = conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, HAS_NBR, DMA>;
     static int extra_lds = -1;      // development knob: PCC_CONV_EXTRA_LDS=<bytes> lowers workgroups per CU
     if (extra_lds < 0) { const char* e = getenv("PCC_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
-    const int lds = conv_lds_bytes<BN>() + extra_lds;
+    const int lds = conv_lds_bytes<BM, BN, DMA>() + extra_lds;
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -364,9 +409,12 @@ static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     return PCC_OK;
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_mfma(const ConvArgs& a, hipStream_t st) {
-    return a.nbr ? launch_mfma_impl<BN, WAVES_M, WAVES_N, true>(a, st) : launch_mfma_impl<BN, WAVES_M, WAVES_N, false>(a, st);
+    static int dma = -1;      // PCC_CONV_DMA=0 selects the register-staged variant (A/B testing)
+    if (dma < 0) { const char* e = getenv("PCC_CONV_DMA"); dma = e ? atoi(e) : 1; }
+    if (dma) return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true, true>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false, true>(a, st);
+    return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true, false>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false, false>(a, st);
 }
 
 template <int CIN>
@@ -416,9 +464,14 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
     hipStream_t st = as_stream(stream);
     if (cin % 32 == 0) {
         PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd: MFMA path (cin=%d) needs packed weights", cin);
-        if (a.coutp % 128 == 0) return launch_mfma<128, 2, 2>(a, st);
-        if (a.coutp % 64 == 0) return launch_mfma<64, 2, 2>(a, st);
-        return launch_mfma<32, 4, 1>(a, st);
+        // 64-row tiles: 48 KB of LDS per workgroup -> 3 workgroups (12 waves) per CU, and twice as many
+        // tiles per launch (less tail loss on the mid-size layers).  PCC_CONV_BM=128 selects the taller
+        // tile for A/B testing.
+        static int bm = -1;
+        if (bm < 0) { const char* e = getenv("PCC_CONV_BM"); bm = e ? atoi(e) : 64; }
+        if (a.coutp % 128 == 0) return bm == 128 ? launch_mfma<128, 128, 2, 2>(a, st) : launch_mfma<64, 128, 2, 2>(a, st);
+        if (a.coutp % 64 == 0) return bm == 128 ? launch_mfma<128, 64, 2, 2>(a, st) : launch_mfma<64, 64, 2, 2>(a, st);
+        return launch_mfma<128, 32, 4, 1>(a, st);
     }
     PCC_REQUIRE(w != nullptr, "pcc_conv_fwd: thin path (cin=%d) needs raw weights", cin);
     switch (cin) {

@@ -317,7 +317,7 @@ def conv_kernel_name(cin, cout):
     if cin % 32 != 0:
         return f"conv_thin<{cin}>"
     coutp = (cout + 31) // 32 * 32
-    bn = 128 if coutp % 128 == 0 else (64 if coutp % 64 == 0 else 32)
+    bn = 128 if coutp % 128 == 0 else (64 if coutp % 64 == 0 else 32)   # row-tile height is 64 (32-wide: 128)
     return f"conv_mfma<{bn}>"
 
 
