@@ -135,6 +135,15 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
                  const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
                  int32_t act, const float* film, const float* residual, void* stream);
 
+/* Narrow-head convolution, second half (cout <= 4 on wide inputs: the occupancy logit of
+ * model/blocks.py:94-98,142 and the q-map heads).  The caller first computes
+ * scores[i, k*cout + c] = in[i] . W[k][:, c] for every INPUT row with one kernel_size-1 call of
+ * pcc_conv_fwd on the re-laid-out kernel [cin, K*cout]; this call adds, per output row, the
+ * <= K scalars its neighbours contribute: out[j,c] = act(bias[c] + sum_k scores[nbr(j,k), k*cout+c]).
+ * `nbr` is the natural-order table of pcc_kernel_map; `ld` = row stride of scores in floats. */
+int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int32_t K, int32_t cout,
+                       const float* bias, float* out, int64_t n_out, int32_t act, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Row movement: lookup-gather, pruning.
  * ------------------------------------------------------------------------------------- */

@@ -35,6 +35,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_conv_fwd": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                              c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_gather_sum_fwd": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "pcc_gather_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_void_p]),
     "pcc_scatter_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),
     "pcc_compact_rows": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -390,6 +390,31 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// narrow heads (cout <= 4 with wide inputs: the occupancy logit, q-map outputs).  Padding cout to a
+// 32-wide MFMA tile would gather every neighbour row (cin * 4 bytes) to produce a handful of
+// numbers.  Instead: scores[i, k*cout + c] = in[i] . W[k][:, c] is one dense GEMM over the INPUT rows
+// (no gather; run through the MFMA kernel as a kernel_size-1 convolution), and this kernel adds
+// the <= 27 scalars each output row needs:  out[j, c] = bias[c] + sum_k scores[nbr(j,k), k*cout + c].
+// HBM-bound: one 4-byte read per (pair, c) instead of cin * 4 bytes per pair.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict__ scores, int ld,
+                                                         const int32_t* __restrict__ nbr, int K, int cout,
+                                                         const float* __restrict__ bias, float* __restrict__ out,
+                                                         int64_t n_out, int act) {
+    const int64_t total = n_out * cout;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / cout;
+        const int c = (int)(e - row * cout);
+        float acc = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            const int idx = nbr[row * K + k];
+            if (idx >= 0) acc += scores[(int64_t)idx * ld + k * cout + c];
+        }
+        out[e] = apply_act(acc + (bias ? bias[c] : 0.0f), act);
+    }
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR, bool DMA>
 static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
@@ -445,6 +470,18 @@ int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, 
     const int64_t total = (int64_t)K * cinp * coutp;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), w, K, cin,
                        cout, cinp, coutp, w_packed);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int32_t K, int32_t cout, const float* bias,
+                       float* out, int64_t n_out, int32_t act, void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27 && cout >= 1 && ld >= K * cout, "pcc_gather_sum_fwd: bad shape (K=%d cout=%d ld=%d)", K, cout, ld);
+    PCC_REQUIRE(nbr != nullptr, "pcc_gather_sum_fwd: neighbour table required");
+    PCC_REQUIRE(act >= 0 && act <= 2, "pcc_gather_sum_fwd: bad activation %d", act);
+    if (n_out <= 0) return PCC_OK;
+    hipLaunchKernelGGL(gather_sum_kernel, dim3(blocks_for(n_out * cout, 256, 1 << 20)), dim3(256), 0, as_stream(stream),
+                       scores, ld, nbr, K, cout, bias, out, n_out, act);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

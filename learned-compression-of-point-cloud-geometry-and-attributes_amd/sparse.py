@@ -276,6 +276,8 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     w, wp, bias = layer.weights(out_channels)
     cin = x_feats.shape[1]
     cout = w.shape[-1]
+    if ksize > 1 and cin % 32 == 0 and cout <= NARROW_HEAD_MAX_COUT and film is None and residual is None:
+        return _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels)
     order = gmask = None
     if ksize == 1:
         nbr = pairs = None
@@ -301,6 +303,34 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
                      gmask))
     return out
 
+
+def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels):
+    """cout <= 4 on wide inputs (occupancy logit, q-map heads): per-input-row scores by one dense MFMA
+    GEMM, then a scalar gather-sum per output row (see csrc/conv.hip, gather_sum_kernel)."""
+    L = _lib.lib()
+    w_r, wp_r, bias, K, cout = layer.narrow_weights(out_channels)
+    n_in, cin = x_feats.shape
+    n_out = out_map.n
+    nbr, _, pairs = in_map.kernel_map(out_map, ksize, transposed)
+    ld = K * cout
+    scores = torch.empty((n_in, ld), dtype=torch.float32, device=x_feats.device)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
+    prof = PROFILER
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.pcc_conv_fwd(ptr(x_feats), n_in, cin, ptr(w_r), ptr(wp_r), None, None, None, None, 1, ptr(scores), n_in, ld,
+                         ACT_NONE, None, None, _lib.stream()))
+    check(L.pcc_gather_sum_fwd(ptr(scores), ld, ptr(nbr), K, cout, ptr(bias), ptr(out), n_out, act, _lib.stream()))
+    if prof is not None:
+        ev1.record()
+        prof.append((f"narrow_head<{cin}>", cin, cout, pairs, n_out, ev0, ev1, None))
+    return out
+
+
+# Output widths up to this use the narrow-head path (K * cout score columns must fit one 128-wide GEMM tile).
+NARROW_HEAD_MAX_COUT = 4
 
 # Spatial block size (log2, in voxels of the map's stride) inside which rows are ordered by neighbour
 # mask; -1 = order by mask over the whole map (best MFMA tile occupancy, least gather locality).
@@ -376,6 +406,23 @@ class _ConvBase(nn.Module):
             check(L.pcc_conv_pack_weights(ptr(w), K, cin, cout, ptr(wp), _lib.stream()))
         res = (w, wp, b)
         self._packed["w"] = (key, res)
+        return res
+
+    def narrow_weights(self, out_channels=None):
+        """Kernel re-laid-out for the narrow-head path: [1, cin, K*cout] (+ MFMA packing), bias, K, cout."""
+        key = ("narrow", self.kernel._version, self.kernel.data_ptr(), out_channels,
+               None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        hit = self._packed.get("n")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w, _, b = self.weights(out_channels)
+        K, cin, cout = w.shape
+        w_r = w.permute(1, 0, 2).reshape(1, cin, K * cout).contiguous()
+        L = _lib.lib()
+        wp_r = torch.empty(L.pcc_conv_packed_elems(1, cin, K * cout), dtype=torch.float32, device=w.device)
+        check(L.pcc_conv_pack_weights(ptr(w_r), 1, cin, K * cout, ptr(wp_r), _lib.stream()))
+        res = (w_r, wp_r, b, K, cout)
+        self._packed["n"] = (key, res)
         return res
 
     def output_map(self, in_map):
