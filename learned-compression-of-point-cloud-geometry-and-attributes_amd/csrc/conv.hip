@@ -74,8 +74,8 @@ constexpr int A_LD_DMA = 32;   // LDS-DMA image: unpadded 128-B rows, 16-B slots
 template <int BM, int BN, bool DMA>
 constexpr int conv_lds_bytes() { return 2 * (BM * (DMA ? A_LD_DMA : A_LD_REG) + 8 * BN * 4) * (int)sizeof(float); }
 
-// one 128-B line of zeros: the gather source of absent neighbours on the LDS-DMA path
-__device__ float g_zero_line[32] = {0.0f};
+// 1 KB of zeros: the gather source of absent neighbours on the LDS-DMA path
+__device__ float g_zero_line[256] = {0.0f};   // cin <= 256: the per-step channel offset stays inside
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
@@ -205,24 +205,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<f32x4*>(Wb + (t + 256 * j) * 4) = wreg[j];
     };
     // ---- LDS-DMA path ----------------------------------------------------------------------------
-    auto dma_step = [&](int k, int c, const int (&idx)[RPT], int buf) {
-        const int wbase_lds = __builtin_amdgcn_readfirstlane(wid);        // provably wave-uniform LDS bases
+    // Per-lane source row pointers (already at my swizzled 16-B chunk) are recomputed only when the
+    // offset k changes, and the weight-slab lane offsets once per tile: the per-step address work is one
+    // 64-bit add per DMA.  VALU issue is shared with the MFMAs of the co-resident waves, so the ~10
+    // VALU instructions of a full address computation per DMA measurably slow the MFMA stream.
+    const float* a_src[RPT];
+    auto set_a_src = [&](const int (&idx)[RPT]) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const bool ok = rvalid[i] && idx[i] >= 0;
             const int q = gchunk ^ ((grow[i] >> 1) & 7);                  // global chunk for my LDS slot
-            const float* src = ok ? (a.fin + (int64_t)idx[i] * a.cin + c * 32 + q * 4) : (g_zero_line + q * 4);
-            float* dst = As + buf * A_ELEMS + (wbase_lds * RPT + i) * 256;  // + lane * 16 B added by the hardware
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+            a_src[i] = (ok ? (a.fin + (int64_t)idx[i] * a.cin) : g_zero_line) + q * 4;
         }
-        const float* wbase = a.wp + (((int64_t)k * (a.cin / 4) + c * 8) * a.coutp + nt * BN) * 4;
+    };
+    int64_t w_lane_off[W_LOADS];
+#pragma unroll
+    for (int j = 0; j < W_LOADS; ++j) {
+        const int f = t + 256 * j;
+        const int g = f / BN, col = f - g * BN;
+        w_lane_off[j] = ((int64_t)g * a.coutp + nt * BN + col) * 4;
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);               // provably wave-uniform LDS bases
+    auto dma_step = [&](int k, int c, int buf) {
+        if (!(a.debug & 16)) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            float* dst = As + buf * A_ELEMS + (wave_u * RPT + i) * 256;   // + lane * 16 B added by the hardware
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + c * 32), (lds_ptr_t)dst, 16, 0, 0);
+        }
+        }
+        if (a.debug & 32) return;
+        const float* wbase = a.wp + ((int64_t)k * (a.cin / 4) + c * 8) * a.coutp * 4;     // scalar
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) {
-            const int f = t + 256 * j;
-            const int g = f / BN, col = f - g * BN;
-            const float* src = wbase + ((int64_t)g * a.coutp + col) * 4;
-            float* dst = Ws + buf * W_ELEMS + (wbase_lds * 64 + 256 * j) * 4;
-            __builtin_amdgcn_global_load_lds((gbl_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+            float* dst = Ws + buf * W_ELEMS + (wave_u * 64 + 256 * j) * 4;
+            __builtin_amdgcn_global_load_lds((gbl_ptr_t)(wbase + w_lane_off[j]), (lds_ptr_t)dst, 16, 0, 0);
         }
     };
 
@@ -295,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         rem &= rem - 1u;
         int knext = rem ? __builtin_ctz(rem) : -1;
         load_idx(k, idx_cur);
-        if constexpr (DMA) dma_step(k, 0, idx_cur, 0);
+        if constexpr (DMA) { set_a_src(idx_cur); dma_step(k, 0, 0); }
         else { load_step(k, 0, idx_cur); store_step(0); }
         load_idx(knext >= 0 ? knext : k, idx_nxt);
         __syncthreads();        // (emits vmcnt(0): the first DMA / loads have landed)
@@ -308,10 +325,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             if (advance) {
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
+                if constexpr (DMA) set_a_src(idx_cur);
             }
             if (has_next && !(a.debug & 1)) {
                 // buffer cur^1 was last read in the previous step, which every wave has left (barrier)
-                if constexpr (DMA) dma_step(nk, nc, idx_cur, cur ^ 1);
+                if constexpr (DMA) dma_step(nk, nc, cur ^ 1);
                 else load_step(nk, nc, idx_cur);
             }
             // indices of the offset after next: issued a full step (or more) before their first use
@@ -490,6 +508,7 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
                  const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                  int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
     PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd: K=%d out of range", K);
+    PCC_REQUIRE(cin % 32 != 0 || cin <= 256, "pcc_conv_fwd: MFMA path supports cin <= 256 (got %d)", cin);
     PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd: nbr == NULL needs K == 1 and n_in == n_out");
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation %d", act);
     if (n_out <= 0) return PCC_OK;
@@ -501,13 +520,14 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
     hipStream_t st = as_stream(stream);
     if (cin % 32 == 0) {
         PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd: MFMA path (cin=%d) needs packed weights", cin);
-        // 64-row tiles: 48 KB of LDS per workgroup -> 3 workgroups (12 waves) per CU, and twice as many
-        // tiles per launch (less tail loss on the mid-size layers).  PCC_CONV_BM=128 selects the taller
-        // tile for A/B testing.
+        // Row-tile height, measured on MI355X: 128-wide outputs run best with 64-row tiles (48 KB of LDS per
+        // workgroup -> 3 workgroups per CU, twice the tiles per launch -> less tail loss on mid-size layers);
+        // 64-wide outputs with 128-row tiles (half the weight-slab traffic per MFMA).  PCC_CONV_BM=64|128
+        // forces one height for A/B testing.
         static int bm = -1;
-        if (bm < 0) { const char* e = getenv("PCC_CONV_BM"); bm = e ? atoi(e) : 64; }
+        if (bm < 0) { const char* e = getenv("PCC_CONV_BM"); bm = e ? atoi(e) : 0; }
         if (a.coutp % 128 == 0) return bm == 128 ? launch_mfma<128, 128, 2, 2>(a, st) : launch_mfma<64, 128, 2, 2>(a, st);
-        if (a.coutp % 64 == 0) return bm == 128 ? launch_mfma<128, 64, 2, 2>(a, st) : launch_mfma<64, 64, 2, 2>(a, st);
+        if (a.coutp % 64 == 0) return bm == 64 ? launch_mfma<64, 64, 2, 2>(a, st) : launch_mfma<128, 64, 2, 2>(a, st);
         return launch_mfma<128, 32, 4, 1>(a, st);
     }
     PCC_REQUIRE(w != nullptr, "pcc_conv_fwd: thin path (cin=%d) needs raw weights", cin);
