@@ -211,7 +211,7 @@ def main():
                   f"  issued-MFMA TFLOP/s {c['exec_flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}",
                   file=sys.stderr)
         per_step = len(launches) // args.steps
-        for ms, n_, cin, cout, n_out, p, ex in sorted(launches[:per_step], key=lambda t: -t[0])[:16]:
+        for ms, n_, cin, cout, n_out, p, ex in sorted(launches[:per_step], key=lambda t: -t[0])[:int(os.environ.get("PCC_BENCH_TOP", "16"))]:
             print(f"    {n_:14s} {cin:4d}->{cout:<4d} rows {n_out:8d} nbrs/row {p / max(n_out, 1):5.1f}  {ms:7.3f} ms  "
                   f"alg {2.0 * p * cin * cout / ms / 1e9:6.1f} TF/s  issued {ex / ms / 1e9:6.1f} TF/s", file=sys.stderr)
         print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "

@@ -526,6 +526,12 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
         // forces one height for A/B testing.
         static int bm = -1;
         if (bm < 0) { const char* e = getenv("PCC_CONV_BM"); bm = e ? atoi(e) : 0; }
+        // Launches that would not fill the chip (256 CUs x 3 workgroups) with 128-wide tiles are split
+        // into 64-wide column tiles: twice the workgroups, half the MFMAs per step and workgroup.  The
+        // accumulation order of an output element does not depend on the tile shape, so results are
+        // bit-identical across configurations.
+        const int64_t wgs128 = ((a.n_out + 63) / 64) * (a.coutp / 128);
+        if (a.coutp % 128 == 0 && bm == 0 && wgs128 < 768) return launch_mfma<64, 64, 2, 2>(a, st);
         if (a.coutp % 128 == 0) return bm == 128 ? launch_mfma<128, 128, 2, 2>(a, st) : launch_mfma<64, 128, 2, 2>(a, st);
         if (a.coutp % 64 == 0) return bm == 64 ? launch_mfma<64, 64, 2, 2>(a, st) : launch_mfma<128, 64, 2, 2>(a, st);
         return launch_mfma<128, 32, 4, 1>(a, st);

@@ -116,7 +116,7 @@ class CoordMap:
         """(nbr int32 [N_out, K], row_mask int32 [N_out], pair_count int64[1]) for input=self, output=out_map."""
         key = ("kmap", id(out_map), ksize, transposed)
         hit = self._cache.get(key)
-        if hit is not None and hit[0] is out_map:
+        if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
             return hit[1:]
         keys, vals, cap = self.table()
         K = ksize ** 3
@@ -127,7 +127,9 @@ class CoordMap:
         step = self.stride // 2 if transposed else self.stride
         check(_lib.lib().pcc_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step,
                                         -1 if transposed else 1, ptr(nbr), ptr(row_mask), ptr(pairs), _lib.stream()))
-        self._cache[key] = (out_map, nbr, row_mask, pairs)   # keeps out_map alive so id() stays unique
+        # keep out_map alive so its id() stays unique -- except for self (that would be a reference
+        # cycle holding gigabytes of device memory until the cyclic GC runs)
+        self._cache[key] = (None if out_map is self else out_map, nbr, row_mask, pairs)
         return nbr, row_mask, pairs
 
     def ordered_kernel_map(self, out_map, ksize, transposed=False):
@@ -137,7 +139,7 @@ class CoordMap:
         that 32-row MFMA tiles skip the offsets none of their rows has."""
         key = ("okmap", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)
         hit = self._cache.get(key)
-        if hit is not None and hit[0] is out_map:
+        if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
             return hit[1:]
         nbr, row_mask, pairs = self.kernel_map(out_map, ksize, transposed)
         L = _lib.lib()
@@ -151,7 +153,7 @@ class CoordMap:
         check(L.pcc_order_rows_by_mask(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
                                        ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(scratch), nbytes,
                                        _lib.stream()))
-        self._cache[key] = (out_map, nbr_sorted, order, gmask, pairs)
+        self._cache[key] = (None if out_map is self else out_map, nbr_sorted, order, gmask, pairs)
         return nbr_sorted, order, gmask, pairs
 
     def count_per_batch(self):
