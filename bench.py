@@ -217,8 +217,7 @@ def main():
         print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "
               f"t_enc {t_enc / args.steps * 1e3:.1f} ms  t_dec {t_dec / args.steps * 1e3:.1f} ms", file=sys.stderr)
 
-    from oracle.codec import count_bits       # pure-python bit counter (utils.py:30-51); checker side only
-    bpp = count_bits(last["strings"]) / N
+    bpp = pcc_amd.utils.count_bits(last["strings"]) / N
     out = {
         "metric": "encode+decode Mpoints/sec",
         "value": n_total * args.steps / elapsed / 1e6,

@@ -15,6 +15,6 @@ from .blocks import ScaledBlock, GenerativeUpBlock, ConditionEncoder  # noqa: F4
 from .transforms import AnalysisTransform, SparseSynthesisTransform  # noqa: F401
 from .entropy_models import MeanScaleHyperprior_Map  # noqa: F401
 from .model import ColorModel  # noqa: F401
-from . import synthetic  # noqa: F401
+from . import synthetic, utils, parallel  # noqa: F401
 
 __all__ = ["ColorModel", "SparseTensor", "CoordMap", "build", "lib"]

@@ -56,3 +56,11 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
                 assert "oracle/" not in src or f.endswith(".md"), f
+
+
+def test_bench_uses_the_oracle_only_in_its_cpu_baseline_leg():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src.split("def cpu_baseline(")[1].split("\ndef main(")[0]
+    rest = src.replace(body, "")
+    assert "oracle" in body
+    assert not re.search(r"^\s*(from|import)\s+oracle\b", rest, flags=re.M)

@@ -167,3 +167,24 @@ def test_block_partition_mode_vs_oracle_with_same_partition(pcc, model, oracle_c
     assert abs(bits - o_bits) <= 3e-3 * o_bits + 64
     m, om = pc_metrics(pts, rec), pc_metrics(pts, o_rec)
     assert abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]) <= 2e-2 and abs(m["sym_y_psnr"] - om["sym_y_psnr"]) <= 2e-2
+
+
+@pytest.mark.parametrize("n_pts", [1, 7, 70])
+def test_tiny_clouds(pcc, model, oracle_codec, n_pts):
+    """Ragged edge: fewer points than one MFMA tile, single-voxel latents, k = 1."""
+    rng = np.random.default_rng(n_pts)
+    xyz = np.unique(rng.integers(8, 24, (n_pts * 3, 3)), axis=0)[:n_pts].astype(np.float32)
+    rgb = (rng.integers(0, 256, (xyz.shape[0], 3)) / 255.0).astype(np.float32)
+    pts = np.concatenate([xyz, rgb], axis=1)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.3, 0.8)
+    strings, shape, k, coordinates = _compress(pcc, model, pts, qc, qf)
+    o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
+    assert shape == o_shape and k == o_k
+    assert set(map(tuple, coordinates.cpu().numpy().tolist())) == set(map(tuple, o_coords.tolist()))
+    rec = model.decompress(coordinates=coordinates, strings=strings, shape=shape, k=k).cpu().numpy()
+    o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+    assert rec.shape == o_rec.shape == (pts.shape[0], 6)
+    assert abs(count_bits(strings) - count_bits(o_strings)) <= 64
+    # with a handful of points every decoded voxel should agree unless a top-k near-tie flips
+    a, b = set(map(tuple, rec[:, :3].tolist())), set(map(tuple, o_rec[:, :3].tolist()))
+    assert len(a ^ b) <= 2
