@@ -188,3 +188,29 @@ def test_tiny_clouds(pcc, model, oracle_codec, n_pts):
     # with a handful of points every decoded voxel should agree unless a top-k near-tie flips
     a, b = set(map(tuple, rec[:, :3].tolist())), set(map(tuple, o_rec[:, :3].tolist()))
     assert len(a ^ b) <= 2
+
+
+def test_full_size_frame_properties(pcc, model):
+    """BASELINE config 2 (N = 850,824), size-independent properties instead of an oracle run:
+    determinism (same bytes twice, same reconstruction twice), header facts, k consistency,
+    unique decoded voxels, 8-bit colours."""
+    syn = pcc.synthetic
+    pts = syn.sphere_shell(**syn.CONFIG2)
+    assert pts.shape[0] == 850_824                                    # SURVEY.md §8d
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    s1, shape, k, coords = _compress(pcc, model, pts, qc, qf)
+    s2, shape2, k2, coords2 = _compress(pcc, model, pts, qc, qf)
+    assert s1 == s2 and shape == shape2 and k == k2 and torch.equal(coords, coords2)
+    assert k[2] == [pts.shape[0]] and k[0][0] < k[1][0] < k[2][0]
+    c8 = coords.cpu().numpy()
+    assert (c8[:, 1:] % 8 == 0).all() and len(set(map(tuple, c8.tolist()))) == c8.shape[0]
+    rec = model.decompress(coordinates=coords, strings=s1, shape=shape, k=k)
+    rec2 = model.decompress(coordinates=coords, strings=s2, shape=shape, k=k)
+    assert torch.equal(rec, rec2)
+    rec = rec.cpu().numpy()
+    assert rec.shape == (pts.shape[0], 6)
+    xyz = rec[:, :3].astype(np.int64)
+    keys = (xyz[:, 0] << 40) | (xyz[:, 1] << 20) | xyz[:, 2]
+    assert np.unique(keys).size == rec.shape[0]
+    col = rec[:, 3:] * 255.0
+    assert col.min() >= 0 and col.max() <= 255 and np.abs(col - np.round(col)).max() < 1e-3
