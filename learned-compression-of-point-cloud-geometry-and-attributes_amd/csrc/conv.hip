@@ -377,34 +377,46 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 // thin path: cin <= 16 (q-map branches, input layers).  HBM/latency bound; W lives in LDS.
 // One thread per (row, output channel); the gathered inputs are broadcast across the row's lanes.
 // ---------------------------------------------------------------------------------------------
-template <int CIN>
+template <int CIN, int CPT>
 __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
+    // one thread = one output row x CPT consecutive output channels: the neighbour index and the CIN
+    // input values are loaded once per offset and reused for CPT FMAs (W rows come from LDS)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int K = a.K, cout = a.cout;
     const int wtotal = K * CIN * cout;
     for (int e = threadIdx.x; e < wtotal; e += 256) smem[e] = a.w[e];
     __syncthreads();
-    const int64_t total = a.n_out * cout;
+    const int groups = cout / CPT;
+    const int64_t total = a.n_out * groups;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t row = e / cout;
-        const int co = (int)(e - row * cout);
-        float acc = 0.0f;
+        const int64_t row = e / groups;
+        const int co = (int)(e - row * groups) * CPT;
+        float acc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = 0.0f;
         for (int k = 0; k < K; ++k) {
             const int idx = a.nbr ? a.nbr[row * K + k] : (int)row;
             if (idx < 0) continue;
-            const float* src = a.fin + (int64_t)idx * CIN;
+            float in[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) in[ci] = a.fin[(int64_t)idx * CIN + ci];
             const float* wk = smem + (k * CIN) * cout + co;
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) acc = fmaf(src[ci], wk[ci * cout], acc);
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int j = 0; j < CPT; ++j) acc[j] = fmaf(in[ci], wk[ci * cout + j], acc[j]);
         }
-        float v = acc + (a.bias ? a.bias[co] : 0.0f);
-        if (a.film) {
-            const float* fr = a.film + row * (2 * (int64_t)cout);
-            v = v * fr[co] + fr[cout + co];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            float v = acc[j] + (a.bias ? a.bias[co + j] : 0.0f);
+            if (a.film) {
+                const float* fr = a.film + row * (2 * (int64_t)cout);
+                v = v * fr[co + j] + fr[cout + co + j];
+            }
+            v = apply_act(v, a.act);
+            if (a.residual) v += a.residual[row * cout + co + j];
+            a.fout[row * cout + co + j] = v;
         }
-        v = apply_act(v, a.act);
-        if (a.residual) v += a.residual[e];
-        a.fout[e] = v;
     }
 }
 
@@ -464,8 +476,13 @@ template <int CIN>
 static int launch_thin(const ConvArgs& a, hipStream_t st) {
     const size_t lds = (size_t)a.K * CIN * a.cout * sizeof(float);
     PCC_REQUIRE(lds <= 64 * 1024, "conv(thin): weights %zu B exceed LDS budget (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
-    const int64_t total = a.n_out * a.cout;
-    hipLaunchKernelGGL(conv_thin_kernel<CIN>, dim3(blocks_for(total, 256, 1 << 20)), dim3(256), lds, st, a);
+    // channels per thread: the largest of 8, 4, 2, 1 dividing cout
+    const int cpt = (a.cout % 8 == 0) ? 8 : (a.cout % 4 == 0) ? 4 : (a.cout % 2 == 0) ? 2 : 1;
+    const unsigned nb = blocks_for(a.n_out * (a.cout / cpt), 256, 1 << 20);
+    if (cpt == 8) hipLaunchKernelGGL((conv_thin_kernel<CIN, 8>), dim3(nb), dim3(256), lds, st, a);
+    else if (cpt == 4) hipLaunchKernelGGL((conv_thin_kernel<CIN, 4>), dim3(nb), dim3(256), lds, st, a);
+    else if (cpt == 2) hipLaunchKernelGGL((conv_thin_kernel<CIN, 2>), dim3(nb), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((conv_thin_kernel<CIN, 1>), dim3(nb), dim3(256), lds, st, a);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
