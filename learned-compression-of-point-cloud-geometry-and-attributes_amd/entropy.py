@@ -344,14 +344,39 @@ class GaussianConditional(_EntropyModelBase):
 
     def decompress_features(self, strings, params, c):
         """params rows must be in the bitstream's row order.  -> y_hat [N, C]."""
+        return self.decompress_features_async(strings, params, c)()
+
+    def decompress_features_async(self, strings, params, c):
+        """Start decoding y: indexes are built on the GPU and copied to the host, then the serial rANS
+        decode runs on a worker thread (the C call releases the GIL).  Returns a function that joins the
+        thread, uploads the symbols and returns y_hat [N, C]; in between the caller can enqueue GPU
+        work that does not depend on y (h_q, kernel maps of the first synthesis stage)."""
+        import threading
         n = params.shape[0]
         dev = params.device
-        idx = self.indexes_for(params, c)
+        idx_host = _to_host(self.indexes_for(params, c), "gc_idx")
         cdf, cdf_len, off = self.tables()
-        sym = _to_device(_rans_decode(strings[0], _to_host(idx, "gc_idx"), cdf, cdf_len, off).reshape(c, n), dev, "gc_sym_up")
-        yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
-        check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
-        return yhat
+        box = {}
+
+        def work():
+            try:
+                box["sym"] = _rans_decode(strings[0], idx_host, cdf, cdf_len, off)
+            except BaseException as e:      # re-raised on the caller's thread
+                box["err"] = e
+
+        th = threading.Thread(target=work, name="pcc-rans-decode")
+        th.start()
+
+        def finish():
+            th.join()
+            if "err" in box:
+                raise box["err"]
+            sym = _to_device(box["sym"].reshape(c, n), dev, "gc_sym_up")
+            yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
+            check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
+            return yhat
+
+        return finish
 
     def forward_features(self, y_feats, params):
         n, c = y_feats.shape
