@@ -190,11 +190,14 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
         # same command, reduced by tools/pmc_traffic.py and committed under profiles/
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic_conv_mfma128.json")
-        if dom_name == "conv_mfma<128>" and args.workload == "config2" and os.path.exists(tfile):
+        tfile = os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")
+        if args.workload == "config2" and os.path.exists(tfile):
             with open(tfile) as f:
-                traffic = json.load(f)["traffic_bytes_per_launch"]
-            traffic_src = "profiles/r01_traffic_conv_mfma128.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 gfx950 correction)"
+                tj = json.load(f)
+            if tj["kernel"] in dom_name:
+                traffic = tj["traffic_bytes_per_launch"]
+                traffic_src = ("profiles/r01_traffic_dominant_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                               "this command, FETCH x2 gfx950 correction)")
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                     "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
@@ -206,13 +209,13 @@ def main():
     if args.breakdown and rank == 0:
         tot_ms = sum(c["ms"] for c in classes.values())
         for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
-            print(f"  {n_:16s} launches/step {c['launches'] / args.steps:6.1f}  ms/step {c['ms'] / args.steps:8.2f} "
+            print(f"  {n_:52s} launches/step {c['launches'] / args.steps:6.1f}  ms/step {c['ms'] / args.steps:8.2f} "
                   f"GFLOP/step {c['flops'] / args.steps / 1e9:9.1f}  TFLOP/s {c['flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}"
                   f"  issued-MFMA TFLOP/s {c['exec_flops'] / max(c['ms'], 1e-9) / 1e9:7.2f}",
                   file=sys.stderr)
         per_step = len(launches) // args.steps
         for ms, n_, cin, cout, n_out, p, ex in sorted(launches[:per_step], key=lambda t: -t[0])[:int(os.environ.get("PCC_BENCH_TOP", "16"))]:
-            print(f"    {n_:14s} {cin:4d}->{cout:<4d} rows {n_out:8d} nbrs/row {p / max(n_out, 1):5.1f}  {ms:7.3f} ms  "
+            print(f"    {n_[:34]:34s} {cin:4d}->{cout:<4d} rows {n_out:8d} nbrs/row {p / max(n_out, 1):5.1f}  {ms:7.3f} ms  "
                   f"alg {2.0 * p * cin * cout / ms / 1e9:6.1f} TF/s  issued {ex / ms / 1e9:6.1f} TF/s", file=sys.stderr)
         print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "
               f"t_enc {t_enc / args.steps * 1e3:.1f} ms  t_dec {t_dec / args.steps * 1e3:.1f} ms", file=sys.stderr)

@@ -301,8 +301,8 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
                          ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     if prof is not None:
         ev1.record()
-        prof.append((conv_kernel_name(cin, cout), cin, cout, pairs if pairs is not None else n_out, n_out, ev0, ev1,
-                     gmask))
+        prof.append((conv_kernel_name(cin, cout, n_out, nbr is not None), cin, cout, pairs if pairs is not None else n_out,
+                     n_out, ev0, ev1, gmask))
     return out
 
 
@@ -344,13 +344,21 @@ ORDER_BLOCK_LOG2 = -1
 PROFILER = None
 
 
-def conv_kernel_name(cin, cout):
-    """Which kernel pcc_conv_fwd dispatches to (mirrors csrc/conv.hip)."""
+def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
+    """The kernel pcc_conv_fwd dispatches to, spelled like rocprofv3 prints it (mirrors csrc/conv.hip)."""
     if cin % 32 != 0:
-        return f"conv_thin<{cin}>"
+        cpt = 8 if cout % 8 == 0 else 4 if cout % 4 == 0 else 2 if cout % 2 == 0 else 1
+        return f"conv_thin_kernel<{cin}, {cpt}>"
     coutp = (cout + 31) // 32 * 32
-    bn = 128 if coutp % 128 == 0 else (64 if coutp % 64 == 0 else 32)   # row-tile height is 64 (32-wide: 128)
-    return f"conv_mfma<{bn}>"
+    if coutp % 128 == 0:
+        bm, bn = (64, 64) if ((n_out + 63) // 64) * (coutp // 128) < 768 else (64, 128)
+    elif coutp % 64 == 0:
+        bm, bn = 128, 64
+    else:
+        bm, bn = 128, 32
+    wm, wn = (4, 1) if bn == 32 else (2, 2)
+    return f"conv_mfma_kernel<{bm}, {bn}, {wm}, {wn}, {'true' if has_nbr else 'false'}, true>"
+
 
 
 # ---------------------------------------------------------------------------------------------
