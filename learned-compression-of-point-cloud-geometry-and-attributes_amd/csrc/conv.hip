@@ -262,6 +262,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const float* Ab = As + buf * A_ELEMS + (wrow + r) * A_LD;
         const float* Wb = Ws + buf * W_ELEMS + (h * BN + wcol + r) * 4;
         f32x4 av[2][MT], bv[2][NT];
+        // MFMA-issuing waves outrank the waves busy with DMA issue / address math on the same SIMD (+3-4 %)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
             if ((LIVE >> m) & 1u) av[0][m] = *reinterpret_cast<const f32x4*>(Ab + 32 * m * A_LD + a_off[0]);
@@ -287,6 +289,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                         if ((LIVE >> m) & 1u)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     auto compute = [&](int buf, int k) {
         unsigned live = 0;
