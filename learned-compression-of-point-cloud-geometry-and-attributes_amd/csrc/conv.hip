@@ -38,7 +38,7 @@ struct ConvArgs {
     const float* residual;  // [n_out, cout] or null
     int64_t n_in, n_out;
     int cin, cout, coutp, K, act;
-    int debug;   // development ablations (PCC_CONV_DEBUG): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
+    int debug;   // development ablations, compiled in only with -DPCC_CONV_ABLATE (PCC_CONV_DEBUG): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -68,6 +68,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------
 // MFMA path
 // ---------------------------------------------------------------------------------------------
+// The ablation switches cost ~3 % when compiled in (branches split the scheduling regions of the main loop)
+#ifdef PCC_CONV_ABLATE
+#define DBG(a) ((a).debug)
+#else
+#define DBG(a) 0
+#endif
 constexpr int A_LD_REG = 36;   // register-staged image: 32 + 4 pad floats per row -> conflict-free ds_read_b128
 constexpr int A_LD_DMA = 32;   // LDS-DMA image: unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
 
@@ -227,14 +233,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);               // provably wave-uniform LDS bases
     auto dma_step = [&](int k, int c, int buf) {
-        if (!(a.debug & 16)) {
+        if (!(DBG(a) & 16)) {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             float* dst = As + buf * A_ELEMS + (wave_u * RPT + i) * 256;   // + lane * 16 B added by the hardware
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + c * 32), (lds_ptr_t)dst, 16, 0, 0);
         }
         }
-        if (a.debug & 32) return;
+        if (DBG(a) & 32) return;
         const float* wbase = a.wp + ((int64_t)k * (a.cin / 4) + c * 8) * a.coutp * 4;     // scalar
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) {
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 for (int i = 0; i < RPT; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
                 if constexpr (DMA) set_a_src(idx_cur);
             }
-            if (has_next && !(a.debug & 1)) {
+            if (has_next && !(DBG(a) & 1)) {
                 // buffer cur^1 was last read in the previous step, which every wave has left (barrier)
                 if constexpr (DMA) dma_step(nk, nc, cur ^ 1);
                 else load_step(nk, nc, idx_cur);
@@ -340,9 +346,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             int kn2 = knext;
             if (advance) { rem2 &= rem2 - 1u; kn2 = rem2 ? __builtin_ctz(rem2) : -1; }
             load_idx(kn2 >= 0 ? kn2 : k, idx_nxt);
-            if (!(a.debug & 8)) compute(cur, k);
-            if constexpr (!DMA) { if (has_next && !(a.debug & 2)) store_step(cur ^ 1); }
-            if (!(a.debug & 4)) __syncthreads();     // vmcnt(0) + lgkmcnt(0) + barrier: next image complete
+            if (!(DBG(a) & 8)) compute(cur, k);
+            if constexpr (!DMA) { if (has_next && !(DBG(a) & 2)) store_step(cur ^ 1); }
+            if (!(DBG(a) & 4)) __syncthreads();     // vmcnt(0) + lgkmcnt(0) + barrier: next image complete
             if (!has_next) break;
             if (advance) { k = nk; rem = rem2; knext = kn2; }
             c = nc;
@@ -374,6 +380,285 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// MFMA path, buffer-addressed (the default).  Same tiling, LDS image, accumulation order and
+// epilogue as conv_mfma_kernel above — results are bit-identical — but the main loop is stripped of
+// everything that competes with the MFMA stream for issue slots:
+//   * gathers and weight slabs are `buffer_load_dwordx4 ... lds` with a lane-constant 32-bit VGPR
+//     offset and a scalar per-step offset: no 64-bit VALU address per DMA.  Absent neighbours and
+//     rows past n_out use an out-of-range offset; the buffer unit returns zeros for those lanes,
+//     so no zero line and no select are needed;
+//   * cin / 32 (CCH) is a template parameter: the steps of one kernel offset are straight-line code,
+//     the LDS buffer parity of every step is a compile-time constant and all fragment addresses are
+//     lane constants computed once per tile (zero VALU address work per step);
+//   * neighbour indices are fetched once per offset (in the offset's last step, one offset ahead),
+//     unconditionally: a load under a branch makes hipcc wait for it at the join.
+// Measured on MI355X (tools/micro/mfma_buf.hip): the bare loop reaches 146-148 TFLOP/s of the
+// 157 TFLOP/s fp32 MFMA peak; with 64-bit global LDS-DMA addressing it stops at 136-139.
+// Limits: fin, nbr and the packed weights must each be < 4 GiB (32-bit buffer offsets); larger
+// operands take conv_mfma_kernel.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t BUF_OOB = 0xFFFFF000u;       // voffset of lanes that must read zeros (>= num_records)
+[[maybe_unused]] constexpr uint32_t BUF_FLAGS = 0x00020000u;     // raw buffer, 32-bit elements (gfx9 family word 3)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR>
+__global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)           // the buffer builtins exist in the device pass only; the host pass needs just the stub
+    constexpr int RPT = BM / 32;              // gather DMAs per thread and step (8 lanes per row)
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
+    constexpr int MT = WM / 32, NT = WN / 32;
+    constexpr int A_ELEMS = BM * 32;          // unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
+    constexpr int W_ELEMS = 8 * BN * 4;
+    constexpr int W_LOADS = (8 * BN) / 256;
+    static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && MT <= 2 && NT >= 1 && W_LOADS >= 1, "bad tiling");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Ws = smem + 2 * A_ELEMS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wid = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wrow = (wid / WAVES_N) * WM, wcol = (wid % WAVES_N) * WN;
+
+    const int ntiles_n = a.coutp / BN;
+    const int64_t tile = blockIdx.x / ntiles_n;
+    const int nt = blockIdx.x - (int)(tile * ntiles_n);
+    const int64_t row0 = tile * BM;
+    const int K = a.K;
+
+    uint32_t tmask, mmask[MT];
+    {
+        const uint32_t all = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+        if (a.gmask) {
+            const int64_t g0 = row0 >> 5;
+            const int64_t ng = (a.n_out + 31) >> 5;
+            tmask = 0u;
+#pragma unroll
+            for (int g = 0; g < BM / 32; ++g) tmask |= (g0 + g < ng) ? (a.gmask[g0 + g] & all) : 0u;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const int64_t g = g0 + (wrow >> 5) + m;
+                const uint32_t v = (g < ng) ? (a.gmask[g] & all) : 0u;
+                mmask[m] = __builtin_amdgcn_readfirstlane(v);
+            }
+        } else {
+            tmask = all;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) mmask[m] = all;
+        }
+        tmask = __builtin_amdgcn_readfirstlane(tmask);
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+
+    if (tmask != 0u) {
+        __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 4), BUF_FLAGS);
+        __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(a.wp), 0, (int)((uint32_t)K * a.cin * a.coutp * 4), BUF_FLAGS);
+        __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int32_t*>(a.nbr), 0, HAS_NBR ? (int)(uint32_t)(a.n_out * K * 4) : 0, BUF_FLAGS);
+
+        // gather roles: one wave-instruction fills 1 KB = 8 consecutive rows; wave w owns rows
+        // [w BM/4, (w+1) BM/4) of the image; lane -> (row, 16-B slot)
+        const int gchunk = t & 7;
+        uint32_t q16[RPT], n_voff[RPT], a_voff[RPT];
+        int idx_nxt[RPT];
+        bool rvalid[RPT];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int grow = wid * (BM / 4) + 8 * i + (lane >> 3);
+            const int64_t pos = row0 + grow;
+            rvalid[i] = pos < a.n_out;
+            const int64_t ps = rvalid[i] ? pos : a.n_out - 1;
+            q16[i] = (uint32_t)((gchunk ^ ((grow >> 1) & 7)) * 16);     // global chunk held by my LDS slot
+            n_voff[i] = (uint32_t)(ps * K * 4);
+            idx_nxt[i] = (int)ps;                                        // identity map when nbr == NULL
+        }
+        uint32_t w_voff[W_LOADS];
+#pragma unroll
+        for (int j = 0; j < W_LOADS; ++j) {
+            const int f = t + 256 * j;
+            const int g = f / BN, col = f - g * BN;
+            w_voff[j] = (uint32_t)((g * a.coutp + nt * BN + col) * 16);
+        }
+        const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+        const uint32_t w_kstride = (uint32_t)(a.cin / 4) * a.coutp * 16;   // bytes per kernel offset
+        const uint32_t w_cstride = (uint32_t)8 * a.coutp * 16;             // bytes per 32-channel chunk
+        const uint32_t a_row_bytes = (uint32_t)a.cin * 4;
+
+        auto load_idx = [&](int k) {
+            if constexpr (HAS_NBR) {
+#pragma unroll
+                for (int i = 0; i < RPT; ++i)
+                    idx_nxt[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsrc_n, n_voff[i], k * 4, 0);
+            }
+        };
+        auto set_src = [&](bool real) {        // idx_nxt -> byte offsets of my gather rows (or out of range -> zeros)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const bool ok = real && rvalid[i] && idx_nxt[i] >= 0;
+                a_voff[i] = ok ? (uint32_t)idx_nxt[i] * a_row_bytes + q16[i] : BUF_OOB;
+            }
+        };
+        auto dma = [&](int k, auto cc, auto bufc) {
+            constexpr int c = decltype(cc)::value;
+            constexpr int buf = decltype(bufc)::value;
+#pragma unroll
+            for (int i = 0; i < RPT; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(As + buf * A_ELEMS + (wave_u * RPT + i) * 256), 16,
+                                                         a_voff[i], c * 128, 0, 0);
+            const uint32_t wso = (uint32_t)k * w_kstride + (uint32_t)c * w_cstride;
+#pragma unroll
+            for (int j = 0; j < W_LOADS; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(Ws + buf * W_ELEMS + (wave_u * 64 + 256 * j) * 4), 16,
+                                                         w_voff[j], wso, 0, 0);
+        };
+
+        // lane-constant LDS byte addresses of my fragments in both buffers.  Lane (r, h) reads, for
+        // sub-block kk, the 16-B chunk 2 kk + h of row wrow + 32 m + r; its slot is chunk ^ ((r >> 1) & 7).
+        const int sw = (r >> 1) & 7;
+        uint32_t a_addr[2][4], w_addr[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                a_addr[b][kk] = (uint32_t)((b * A_ELEMS + (wrow + r) * 32 + (((kk ^ (sw >> 1)) << 1) | (h ^ (sw & 1))) * 4) * 4);
+            w_addr[b] = (uint32_t)((2 * A_ELEMS + b * W_ELEMS + (h * BN + wcol + r) * 4) * 4);
+        }
+        auto lds4 = [&](uint32_t addr) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(smem) + addr); };
+
+        auto compute_live = [&](auto bufc, auto live_tag) {
+            constexpr int buf = decltype(bufc)::value;
+            constexpr unsigned LIVE = decltype(live_tag)::value;
+            f32x4 av[2][MT], bv[2][NT];
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+                if ((LIVE >> m) & 1u) av[0][m] = lds4(a_addr[buf][0] + 32 * m * 32 * 4);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) bv[0][n] = lds4(w_addr[buf] + 32 * n * 16);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cb = kk & 1, nb = cb ^ 1;
+                if (kk + 1 < 4) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+                        if ((LIVE >> m) & 1u) av[nb][m] = lds4(a_addr[buf][kk + 1] + 32 * m * 32 * 4);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) bv[nb][n] = lds4(w_addr[buf] + (2 * (kk + 1) * BN + 32 * n) * 16);
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if ((LIVE >> m) & 1u)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        auto compute = [&](auto bufc, unsigned live) {        // live: wave-uniform, bit m = 32-row tile m has this offset
+            if constexpr (MT == 1) {
+                if (live) compute_live(bufc, std::integral_constant<unsigned, 1u>{});
+            } else {
+                if (live == 3u) compute_live(bufc, std::integral_constant<unsigned, 3u>{});
+                else if (live == 1u) compute_live(bufc, std::integral_constant<unsigned, 1u>{});
+                else if (live == 2u) compute_live(bufc, std::integral_constant<unsigned, 2u>{});
+            }
+        };
+
+        // One kernel offset = CCH steps of straight-line code.  Step c computes chunk c from buffer
+        // (P + c) & 1 while the DMAs of the following step fill the other buffer; the offset's last
+        // step starts the next live offset (its indices arrived one offset ago) and fetches the indices
+        // of the one after.  When no offset follows, that step's gather is pointed out of range (no
+        // traffic) so that the code stays branch-free; its image is never read.
+        uint32_t rem = tmask;
+        int k = __builtin_ctz(rem);
+        rem &= rem - 1u;
+        auto offset_body = [&](auto pc) {
+            constexpr int P = decltype(pc)::value;
+            const int knext = rem ? __builtin_ctz(rem) : -1;
+            const uint32_t rem2 = rem & (rem - 1u);
+            const int kn2 = rem2 ? __builtin_ctz(rem2) : (knext >= 0 ? knext : k);
+            unsigned live = 0;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) live |= ((mmask[m] >> k) & 1u) << m;
+            static_for<0, CCH>([&](auto cc) {
+                constexpr int c = decltype(cc)::value;
+                constexpr int buf = (P + c) & 1;
+                if constexpr (c + 1 < CCH) {
+                    dma(k, std::integral_constant<int, c + 1>{}, std::integral_constant<int, buf ^ 1>{});
+                } else {
+                    set_src(knext >= 0);
+                    dma(knext >= 0 ? knext : k, std::integral_constant<int, 0>{}, std::integral_constant<int, buf ^ 1>{});
+                    load_idx(kn2);
+                }
+                compute(std::integral_constant<int, buf>{}, live);
+                __syncthreads();       // vmcnt(0) + barrier: the next image is complete, this one is free
+            });
+            const bool more = knext >= 0;
+            k = more ? knext : k;
+            rem = rem2;
+            return more;
+        };
+
+        load_idx(k);
+        set_src(true);
+        dma(k, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        load_idx(rem ? __builtin_ctz(rem) : k);
+        __syncthreads();
+        while (true) {
+            if (!offset_body(std::integral_constant<int, 0>{})) break;
+            if constexpr (CCH & 1) {
+                if (!offset_body(std::integral_constant<int, 1>{})) break;
+            }
+        }
+    }
+
+    // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r] per 32x32 tile
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int col = nt * BN + wcol + 32 * n + r;
+            if (col >= a.cout) continue;
+            const float bcol = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int64_t pos = row0 + wrow + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                if (pos >= a.n_out) continue;
+                const int64_t row = a.order ? a.order[pos] : pos;
+                float v = acc[m][n][reg] + bcol;
+                if (a.film) {
+                    const float* fr = a.film + row * (2 * (int64_t)a.cout);
+                    v = v * fr[col] + fr[a.cout + col];
+                }
+                v = apply_act(v, a.act);
+                if (a.residual) v += a.residual[row * a.cout + col];
+                a.fout[row * a.cout + col] = v;
+            }
+        }
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,12 +752,46 @@ static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     return PCC_OK;
 }
 
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR>
+static int launch_mfma_buf_impl(const ConvArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR>;
+    const int lds = conv_lds_bytes<BM, BN, true>();
+    if (!attr_set) {
+        PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int64_t tiles = (a.n_out + BM - 1) / BM;
+    const int64_t blocks = tiles * (a.coutp / BN);
+    PCC_REQUIRE(blocks < (1ll << 31), "conv: grid too large");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, a);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+// 32-bit buffer offsets: every operand the buffer path addresses must stay below BUF_OOB bytes
+static bool fits_buffer_path(const ConvArgs& a) {
+    const uint64_t lim = BUF_OOB;
+    return (uint64_t)a.n_in * a.cin * 4 <= lim && (uint64_t)a.n_out * a.K * 4 <= lim && (uint64_t)a.K * a.cin * a.coutp * 4 <= lim;
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_mfma(const ConvArgs& a, hipStream_t st) {
-    static int dma = -1;      // PCC_CONV_DMA=0 selects the register-staged variant (A/B testing)
-    if (dma < 0) { const char* e = getenv("PCC_CONV_DMA"); dma = e ? atoi(e) : 1; }
-    if (dma) return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true, true>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false, true>(a, st);
-    return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true, false>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false, false>(a, st);
+    static int path = -1;      // PCC_CONV_PATH=global forces the 64-bit-addressed kernel (testing; the >= 4 GiB fallback)
+    if (path < 0) { const char* e = getenv("PCC_CONV_PATH"); path = (e && e[0] == 'g') ? 1 : 0; }
+    if (path == 0 && fits_buffer_path(a)) {
+#define PCC_BUF_CASE(C)                                                                                        \
+    case C:                                                                                                    \
+        return a.nbr ? launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, C, true>(a, st)                          \
+                     : launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, C, false>(a, st);
+        switch (a.cin / 32) {
+            PCC_BUF_CASE(1) PCC_BUF_CASE(2) PCC_BUF_CASE(3) PCC_BUF_CASE(4)
+            PCC_BUF_CASE(5) PCC_BUF_CASE(6) PCC_BUF_CASE(7) PCC_BUF_CASE(8)
+            default: break;
+        }
+#undef PCC_BUF_CASE
+    }
+    return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true, true>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false, true>(a, st);
 }
 
 template <int CIN>

@@ -12,6 +12,8 @@ parameter containers only.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -336,7 +338,7 @@ NARROW_HEAD_MAX_COUT = 4
 
 # Spatial block size (log2, in voxels of the map's stride) inside which rows are ordered by neighbour
 # mask; -1 = order by mask over the whole map (best MFMA tile occupancy, least gather locality).
-ORDER_BLOCK_LOG2 = -1
+ORDER_BLOCK_LOG2 = int(os.environ.get("PCC_ORDER_BLOCK_LOG2", "-1"))
 
 # Optional launch log for bench.py: a list that receives one tuple per convolution launch
 # (kernel class, cin, cout, pairs (device scalar or int), n_out, start event, end event).  The
@@ -357,7 +359,7 @@ def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
     else:
         bm, bn = 128, 32
     wm, wn = (4, 1) if bn == 32 else (2, 2)
-    return f"conv_mfma_kernel<{bm}, {bn}, {wm}, {wn}, {'true' if has_nbr else 'false'}, true>"
+    return f"conv_mfma_buf_kernel<{bm}, {bn}, {wm}, {wn}, {cin // 32}, {'true' if has_nbr else 'false'}>"
 
 
 
