@@ -166,13 +166,15 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
     }
     // Per-table decode state packed back to back (the caller's [n_tables, stride] int32 matrix is
     // ~800 KB, its used prefix a few tens of KB):
-    //   lut[b]  = symbol whose interval contains slot b << 8, bit 15 set when the whole bucket
-    //             [b << 8, (b + 1) << 8) lies inside that symbol (no search needed);
-    //   sf[s]   = start | freq << 16   (one load instead of cdf[s], cdf[s + 1]);
+    //   lut[b]  = start | freq << 16 | symbol << 32 of the symbol whose interval contains slot b << 8,
+    //             bit 47 set when the whole bucket [b << 8, (b + 1) << 8) lies inside that symbol: the
+    //             common case needs ONE dependent load between two states of the decoder (the
+    //             state -> slot -> table -> state chain is what bounds a serial rANS decode);
+    //   sf[s]   = start | freq << 16   (one load instead of cdf[s], cdf[s + 1]) for impure buckets;
     //   cdf[]   = the row itself, for the short forward scan of impure buckets.
     constexpr int kBuckets = 256, kShift = kPrecision - 8;
-    struct DecTable { const uint32_t* cdf; const uint32_t* sf; const uint16_t* lut; int32_t maxv; int32_t offset; };
-    std::vector<uint16_t> lut((size_t)(max_ix + 1) * kBuckets);
+    struct DecTable { const uint32_t* cdf; const uint32_t* sf; const uint64_t* lut; int32_t maxv; int32_t offset; };
+    std::vector<uint64_t> lut((size_t)(max_ix + 1) * kBuckets);
     std::vector<int64_t> row_off((size_t)max_ix + 2, 0);
     for (int32_t t = 0; t <= max_ix; ++t) row_off[(size_t)t + 1] = row_off[(size_t)t] + cdf_sizes[t];
     std::vector<uint32_t> packed((size_t)row_off[(size_t)max_ix + 1] + 1, 0xFFFFFFFFu);   // + sentinel
@@ -191,7 +193,7 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
             const uint32_t slot = (uint32_t)b << kShift;
             while (sidx + 1 < nsym && row[sidx + 1] <= slot) ++sidx;
             const bool pure = row[sidx + 1] >= slot + (1u << kShift);
-            lut[(size_t)t * kBuckets + b] = (uint16_t)(sidx | (pure ? 0x8000 : 0));
+            lut[(size_t)t * kBuckets + b] = (uint64_t)sf[sidx] | ((uint64_t)sidx << 32) | (pure ? (1ull << 47) : 0ull);
         }
         tabs[(size_t)t] = DecTable{row, sf, lut.data() + (size_t)t * kBuckets, cdf_sizes[t] - 2, offsets[t]};
     }
@@ -215,13 +217,14 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
         const DecTable& tb = tabs[(size_t)indexes[i]];
         const int32_t maxv = tb.maxv;
         const uint32_t cf = (uint32_t)(x & 0xFFFFu);
-        const uint32_t e = tb.lut[cf >> kShift];
-        int32_t s = (int32_t)(e & 0x7FFFu);
-        if (!(e & 0x8000u)) {
+        const uint64_t e = tb.lut[cf >> kShift];
+        int32_t s = (int32_t)((e >> 32) & 0x7FFFu);
+        uint32_t sfe = (uint32_t)e;
+        if (!(e >> 47)) {
             // == (first j with cdf[j] > cf) - 1; the row ends with 2^16 > cf, so the scan stops in range
             while (tb.cdf[s + 1] <= cf) ++s;
+            sfe = tb.sf[s];
         }
-        const uint32_t sfe = tb.sf[s];
         x = (uint64_t)(sfe >> 16) * (x >> kPrecision) + cf - (sfe & 0xFFFFu);
         refill();
         int32_t value = s;

@@ -19,6 +19,8 @@ torch.manual_seed(0)
 for cin, cout in shapes:
     F = torch.randn(n, cin, device=dev)
     W = torch.randn(K, cin, cout, device=dev) * 0.05
+    if os.environ.get("ZERO_DATA"):      # does operand toggling (power) change the rate?
+        F.zero_(); W.zero_()
     Wp = torch.empty(L.pcc_conv_packed_elems(K, cin, cout), device=dev)
     check(L.pcc_conv_pack_weights(ptr(W), K, cin, cout, ptr(Wp), _lib.stream()))
     out = torch.empty(n, cout, device=dev)
