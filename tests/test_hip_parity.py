@@ -164,6 +164,8 @@ CONV_SHAPES = [
     (128, 128, 3), (64, 128, 3), (128, 256, 3), (128, 64, 3), (64, 64, 3), (64, 32, 3), (32, 3, 3),
     (128, 2, 3), (64, 2, 3), (192, 256, 3), (128, 1, 3), (128, 128, 1), (16, 16, 1),
     (4, 64, 3), (4, 2, 3), (2, 2, 3), (2, 128, 3), (2, 16, 3), (16, 2, 3), (1, 1, 3),
+    # the remaining cin / 32 instantiations of the MFMA kernel (odd chunk counts alternate the LDS buffer parity)
+    (96, 64, 3), (160, 32, 3), (224, 128, 3), (256, 128, 3),
 ]
 
 
@@ -240,6 +242,42 @@ def test_conv_is_row_order_invariant_bitwise(pcc):
     perm = np.random.default_rng(5).permutation(n)
     b = layer(pcc.SparseTensor(dev(F[torch.from_numpy(perm)]), coordinate_map=pcc.CoordMap(dev(c[perm]), 1))).F.cpu()
     assert torch.equal(a[torch.from_numpy(perm)], b)
+
+
+_PATH_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+import pcc_amd
+torch.manual_seed(3)
+g = np.stack(np.meshgrid(*[np.arange(24)] * 3, indexing="ij"), -1).reshape(-1, 3)
+keep = np.abs(np.linalg.norm(g - 11.5, axis=1) - 9.0) < 1.2
+c = np.concatenate([np.zeros((int(keep.sum()), 1), np.int32), g[keep].astype(np.int32)], 1)
+h = hashlib.sha256()
+for cin, cout in [(128, 128), (64, 64), (96, 32), (128, 256)]:
+    layer = pcc_amd.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).to("cuda:0")
+    F = torch.randn(c.shape[0], cin, device="cuda:0")
+    out = layer(pcc_amd.SparseTensor(F, coordinate_map=pcc_amd.CoordMap(torch.from_numpy(c).to("cuda:0"), 1))).F
+    h.update(out.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_conv_64bit_addressed_fallback_is_bit_identical(pcc):
+    """Operands of 4 GiB and more take conv_mfma_kernel (64-bit LDS-DMA addressing) instead of the
+    buffer-addressed kernel; PCC_CONV_PATH=global forces it.  Same accumulation order -> same bits."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for path in ("buffer", "global"):
+        env = dict(os.environ, PCC_CONV_PATH=path)
+        r = subprocess.run([sys.executable, "-c", _PATH_SCRIPT.format(root=root)], env=env, capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
 
 
 def test_gather_scatter_compact(pcc):
