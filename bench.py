@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="256,100,0.5", help="grid,radius,half_width of the CPU-baseline shell")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
+    ap.add_argument("--file-mode", action="store_true",
+                    help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
 
 
@@ -221,6 +223,31 @@ def main():
               f"t_enc {t_enc / args.steps * 1e3:.1f} ms  t_dec {t_dec / args.steps * 1e3:.1f} ms", file=sys.stderr)
 
     bpp = pcc_amd.utils.count_bits(last["strings"]) / N
+    file_mode = None
+    if args.file_mode and rank == 0:
+        # t_file: the same frame through the container on disk (28-byte header, PCO1 coordinate payload, y, z)
+        import tempfile
+        with tempfile.TemporaryDirectory() as td:
+            path = os.path.join(td, "frame.bin")
+            te, tdc = [], []
+            for it in range(4):
+                Q = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                model.compress(x, Q, path=path)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                rec_f = model.decompress(path=path)
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                if it:
+                    te.append(t1 - t0); tdc.append(t2 - t1)
+            size = os.path.getsize(path)
+            with open(path, "rb") as f:
+                head = f.read(28)
+        import struct
+        coord_bytes = struct.unpack(">7i", head)[1]
+        file_mode = {"t_enc_ms": 1e3 * sum(te) / len(te), "t_dec_ms": 1e3 * sum(tdc) / len(tdc), "file_bytes": size,
+                     "coordinate_payload_bytes": coord_bytes, "bpp_file": 8.0 * size / N,
+                     "decoded_points": int(rec_f.shape[0]),
+                     "note": "coordinate payload = this build's lossless octree (PCO1), not G-PCC"}
     out = {
         "metric": "encode+decode Mpoints/sec",
         "value": n_total * args.steps / elapsed / 1e6,
@@ -244,6 +271,8 @@ def main():
         "conv_gflop_per_step": sum(c["flops"] for c in classes.values()) / args.steps / 1e9,
         "roofline": roofline,
     }
+    if file_mode is not None:
+        out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {n_: t.detach().cpu() for n_, t in model.state_dict().items()}
         out["cpu_baseline"] = cpu_baseline(sd, args.cpu_sample)

@@ -183,6 +183,30 @@ int pcc_sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* scrat
                     int64_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Latent-coordinate side channel of file mode.  Replaces ColorModel.gpcc_encode / gpcc_decode
+ * (model/model.py:318-395), which shell out to the external MPEG G-PCC binary `tmc3`; this is the
+ * build's own lossless octree ("PCO1", NOT G-PCC compatible; container in octree.py).
+ *
+ * pcc_octree_occupancy: coords [n,4] (batch ignored), grid = (c - origin) / stride must lie in
+ *   [0, 2^depth)^3.  Child index per level = (xbit << 2) | (ybit << 1) | zbit.  Level L
+ *   (0 = root .. depth-1) receives one occupancy byte per occupied node, ascending Morton order,
+ *   at occupancy[L * n ...]; level_counts (device, depth + 2 ints) = nodes per level, then the
+ *   number of distinct leaves (== n unless the input holds duplicates), then the number of
+ *   inputs outside the grid / off the stride lattice (must be 0).  origin: 3 host ints.
+ * pcc_octree_expand: the inverse.  occupancy = the levels back to back (device), level_counts
+ *   = depth host int64; writes coords_out [n_points,4] = (batch, x, y, z) in ascending Morton
+ *   order.  The caller has already checked that the popcounts of level L sum to the size of
+ *   level L+1 (n_points for the last); a stream that lies cannot write out of bounds.
+ * ------------------------------------------------------------------------------------- */
+int64_t pcc_octree_scratch_bytes(int64_t n);
+int pcc_octree_occupancy(const int32_t* coords, int64_t n, int32_t stride, const int32_t* origin,
+                         int32_t depth, uint8_t* occupancy, int32_t* level_counts, void* scratch,
+                         int64_t scratch_bytes, void* stream);
+int pcc_octree_expand(const uint8_t* occupancy, const int64_t* level_counts, int32_t depth,
+                      int32_t stride, const int32_t* origin, int32_t batch, int64_t n_points,
+                      int32_t* coords_out, void* scratch, int64_t scratch_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Entropy model, device side (compressai EntropyBottleneck / GaussianConditional,
  * model/entropy_models.py:313,330,352-353,371-372,393,407-408).  Features are [N, C]
  * row-major; symbol / index / likelihood planes are channel-major [C, N] — the order in

@@ -44,6 +44,9 @@ SIGNATURES = {
     "pcc_count_per_batch": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "pcc_sort_scratch_bytes": (c_i64, [c_i64]),
     "pcc_sort_coords": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_octree_scratch_bytes": (c_i64, [c_i64]),
+    "pcc_octree_occupancy": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_octree_expand": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_eb_quantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_eb_dequantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_eb_likelihood": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),

@@ -256,7 +256,7 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
 
 int64_t pcc_sort_scratch_bytes(int64_t n) {
     size_t temp = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
                                        (const int32_t*)nullptr, (int32_t*)nullptr, (int)(n > 0 ? n : 1));
     return align256((int64_t)temp) + 2 * align256(n * 8) + align256(n * 4) + 256;
 }

@@ -4,18 +4,17 @@ Same constructor config, same ``forward`` / ``compress`` / ``decompress`` / ``up
 ``aux_loss`` signatures and return values as the reference, running on libpcc_hip.so.
 
 File mode (``path=...``): the reference shells out to the MPEG G-PCC ``tmc3`` binary for the
-stride-8 latent coordinates (model/model.py:318-395); that binary is not part of this path
+stride-8 latent coordinates (model/model.py:318-395); that binary is external and unavailable
 (SURVEY.md N15, §8f rank 2).  The 28-byte header and payload order of the container are kept
-(model/model.py:241-256); the coordinate payload is written by a small lossless placeholder
-coder (sorted int16 deltas + zlib) and is NOT G-PCC-compatible.
+(model/model.py:241-256); the coordinate payload is written by the build's own lossless octree
+coder (octree.py + csrc/octree.hip, "PCO1"), which is NOT G-PCC-compatible.
 """
 import struct
-import zlib
 
-import numpy as np
 import torch
 import torch.nn as nn
 
+from . import octree
 from . import sparse as sp
 from .entropy_models import MeanScaleHyperprior_Map
 from .sparse import CoordMap, SparseTensor
@@ -23,6 +22,8 @@ from .transforms import AnalysisTransform, SparseSynthesisTransform
 
 
 class ColorModel(nn.Module):
+    LATENT_STRIDE = 8      # three stride-2 stages of g_a (model/transforms.py:75-128)
+
     def __init__(self, config):
         super().__init__()
         self.g_a = AnalysisTransform(config["g_a"])
@@ -94,23 +95,18 @@ class ColorModel(nn.Module):
         return torch.cat([x_hat.C[:, 1:4].to(feats.dtype), feats], dim=1)
 
     # -- container (model/model.py:214-315) --------------------------------------------------------------
-    @staticmethod
-    def _encode_points(points):
-        """Placeholder lossless coder for the stride-8 coordinate list (NOT G-PCC)."""
-        p = points.detach().cpu().numpy()[:, 1:4].astype(np.int64)
-        order = np.lexsort((p[:, 2], p[:, 1], p[:, 0]))
-        p = p[order]
-        d = np.diff(p, axis=0, prepend=np.zeros((1, 3), dtype=np.int64)).astype("<i2")
-        return struct.pack("<I", p.shape[0]) + zlib.compress(d.tobytes(), 9)
+    def gpcc_encode(self, points, directory=None):
+        """model/model.py:318-364: latent coordinates [N,4] -> bytes.  ``directory`` (the reference's
+        scratch location for tmc3's temporary files) is accepted and unused: nothing touches disk."""
+        return octree.encode_coordinates(points, self.LATENT_STRIDE)
 
-    @staticmethod
-    def _decode_points(data):
-        n = struct.unpack("<I", data[:4])[0]
-        d = np.frombuffer(zlib.decompress(data[4:]), dtype="<i2").reshape(n, 3).astype(np.int64)
-        return torch.from_numpy(np.cumsum(d, axis=0).astype(np.float64))
+    def gpcc_decode(self, bin, directory=None):
+        """model/model.py:366-395: bytes -> float64 [N,3] like the reference's PLY read-back (on the
+        model's device, in the stream's Morton order; decompress() re-sorts canonically anyway)."""
+        return octree.decode_coordinates(bin, self.device)[:, 1:4].to(torch.float64)
 
     def save_bitstream(self, path, points, strings, shape, k):
-        pts = self._encode_points(points)
+        pts = self.gpcc_encode(points, path)
         ks = [int(kk[0]) if isinstance(kk, (list, tuple)) else int(kk) for kk in k]
         # 7 x int32, MSB first like the `bitstream` package (SURVEY.md §8c item 6): 28 bytes
         header = struct.pack(">7i", int(shape[0]), len(pts), len(strings[0][0]), len(strings[1][0]), *ks)
@@ -125,4 +121,4 @@ class ColorModel(nn.Module):
         pts = data[o:o + lp]; o += lp
         ys = data[o:o + ly]; o += ly
         zs = data[o:o + lz]
-        return self._decode_points(pts), [[ys], [zs]], [int(nz)], [[int(k0)], [int(k1)], [int(k2)]]
+        return self.gpcc_decode(pts, path), [[ys], [zs]], [int(nz)], [[int(k0)], [int(k1)], [int(k2)]]
