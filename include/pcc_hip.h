@@ -207,6 +207,21 @@ int pcc_octree_expand(const uint8_t* occupancy, const int64_t* level_counts, int
                       int32_t* coords_out, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Quality metrics: nearest-neighbour association on integer grids.  Replaces the open3d KD-tree
+ * queries of PointCloudMetric (metrics/metric.py:36-43).  For every query row (b,x,y,z) finds the
+ * nearest target voxel through the target's hash table (pcc_hash_build): nn_idx = target row,
+ * nn_d2 = squared Euclidean distance (sum over axes, NOT the reference's per-axis mean);
+ * equidistant candidates resolve to the smallest (x,y,z); tie_count / tie_rgb (optional) = number
+ * of equidistant nearest voxels and the sum of their colours (target_rgb [n,3], f64 like the
+ * reference's numpy arrays) for the reference's
+ * tie-averaging mode (metric.py:121-146).  Queries whose neighbour is farther than max_radius
+ * (Chebyshev shells searched: 0..max_radius) get nn_idx = nn_d2 = -1 and must be retried wider.
+ * ------------------------------------------------------------------------------------- */
+int pcc_nn_search(const int32_t* query, int64_t nq, const uint64_t* keys, const int32_t* vals, int64_t cap,
+                  const double* target_rgb, int32_t max_radius, int32_t* nn_idx, int64_t* nn_d2,
+                  int32_t* tie_count, double* tie_rgb, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Entropy model, device side (compressai EntropyBottleneck / GaussianConditional,
  * model/entropy_models.py:313,330,352-353,371-372,393,407-408).  Features are [N, C]
  * row-major; symbol / index / likelihood planes are channel-major [C, N] — the order in

@@ -47,6 +47,8 @@ SIGNATURES = {
     "pcc_octree_scratch_bytes": (c_i64, [c_i64]),
     "pcc_octree_occupancy": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_octree_expand": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_nn_search": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
     "pcc_eb_quantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_eb_dequantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_eb_likelihood": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),

@@ -7,7 +7,7 @@ squared coordinate difference (metric.py:113-119), colours rounded to 8 bit and
 converted with the BT.709 matrix after a truncating uint8 cast
 (metric.py:149-150,171-189), symmetric value = min over the two directions
 (metric.py:72-83).  open3d's KD-tree is replaced by scipy's; ties between
-equidistant neighbours may resolve differently (unpinned).
+equidistant neighbours (KD-tree visiting order in the reference: unpinned) resolve to the smallest (x, y, z).
 Test infrastructure only — see oracle/__init__.py.
 """
 import numpy as np
@@ -36,14 +36,35 @@ def _dedupe(pc):
     return pc[np.sort(first)]
 
 
-def _one_way(a, b, resolution):
+def _one_way(a, b, resolution, average_ties=False, kmax=32):
+    """nearest neighbour of every row of a in b.  Equidistant candidates (common on a lattice; the
+    reference takes whichever its KD-tree visits first, metric.py:36-43) resolve to the smallest
+    (x, y, z).  average_ties restates metric.py:121-146: where several neighbours share the nearest
+    distance the colour becomes (first + sum of all of them) / (count + 1)."""
     tree = cKDTree(b[:, :3])
-    _, nn = tree.query(a[:, :3], k=1)
+    k = min(kmax, b.shape[0])
+    dist, cand = tree.query(a[:, :3], k=k)
+    if k == 1:
+        dist, cand = dist[:, None], cand[:, None]
+    d2c = np.rint(dist ** 2).astype(np.int64)                      # integer grids: exact squared distances
+    best = d2c[:, :1]
+    tie = d2c == best
+    bkey = (b[:, 0].astype(np.int64) << 42) + (b[:, 1].astype(np.int64) << 21) + b[:, 2].astype(np.int64)
+    ck = np.where(tie, bkey[cand], np.iinfo(np.int64).max)
+    nn = cand[np.arange(a.shape[0]), ck.argmin(axis=1)]
     d = ((a[:, :3] - b[nn, :3]) ** 2).mean(axis=1)
     res = {"mse": d.mean(), "hausdorff": d.max()}
     res["psnr_mse"] = 10 * np.log10(resolution ** 2 / res["mse"]) if res["mse"] > 0 else np.inf
+    res["psnr_hausdorff"] = 10 * np.log10(resolution ** 2 / res["hausdorff"]) if res["hausdorff"] > 0 else np.inf
+    b_col = b[nn, 3:6].copy()
+    if average_ties:
+        cnt = tie.sum(axis=1)
+        assert (cnt < k).all() or b.shape[0] <= kmax, "tie set may be truncated: raise kmax"
+        tsum = (b[cand, 3:6] * tie[:, :, None]).sum(axis=1)
+        many = cnt > 1
+        b_col[many] = (b_col[many] + tsum[many]) / (cnt[many] + 1)[:, None]
     a_yuv = rgb_to_yuv(np.clip(np.round(a[:, 3:6] * 255.0) / 255.0, 0.0, 1.0))
-    b_yuv = rgb_to_yuv(np.clip(np.round(b[nn, 3:6] * 255.0) / 255.0, 0.0, 1.0))
+    b_yuv = rgb_to_yuv(np.clip(np.round(b_col * 255.0) / 255.0, 0.0, 1.0))
     e = ((a_yuv - b_yuv) ** 2).mean(axis=0)
     for i, ch in enumerate("yuv"):
         res[f"{ch}_mse"] = e[i]
@@ -51,18 +72,16 @@ def _one_way(a, b, resolution):
     return res
 
 
-def pc_metrics(source, recon, resolution=1023):
-    """source/recon: float [N,6] (xyz voxel coords, rgb in [0,1])."""
+def pc_metrics(source, recon, resolution=1023, average_ties=False):
+    """source/recon: float [N,6] (xyz voxel coords, rgb in [0,1]).  average_ties=False is the
+    reference's compute_pointcloud_metrics(drop_duplicates=True), True its default."""
     a = _dedupe(np.asarray(source, dtype=np.float64))
     b = _dedupe(np.asarray(recon, dtype=np.float64))
-    ab = _one_way(a, b, resolution)
-    ba = _one_way(b, a, resolution)
+    ab = _one_way(a, b, resolution, average_ties)
+    ba = _one_way(b, a, resolution, average_ties)
     out = {}
     for kk in ab:
         out["AB_" + kk] = ab[kk]
         out["BA_" + kk] = ba[kk]
-    out["sym_psnr_mse"] = min(ab["psnr_mse"], ba["psnr_mse"])
-    out["sym_y_psnr"] = min(ab["y_psnr"], ba["y_psnr"])
-    out["sym_u_psnr"] = min(ab["u_psnr"], ba["u_psnr"])
-    out["sym_v_psnr"] = min(ab["v_psnr"], ba["v_psnr"])
+        out["sym_" + kk] = min(ab[kk], ba[kk])
     return out
