@@ -183,6 +183,25 @@ int pcc_sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* scrat
                     int64_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Convolution backward (training path; the reference gets it from MinkowskiEngine's autograd
+ * functions behind every ME.Minkowski*Convolution*, train.py:194-206).
+ *   dX = pcc_conv_fwd over the TRANSPOSED map with transposed weights W^T[k] = W[k]^T:
+ *        pcc_kernel_map_transpose gives nbr_t[i, k] = output row j with nbr[j, k] == i (or -1) and
+ *        the per-input-row offset masks (feed them to pcc_order_rows_by_mask like a forward map).
+ *   dW[k] = sum over the pairs of offset k of X[i]^T dY[j]: pcc_conv_wgrad (nbr / order / group masks
+ *        of the FORWARD map in execution order; order == NULL: natural order).  fp32 MFMA for
+ *        cin, cout multiples of 32, a scalar kernel for thin shapes (cin * cout <= 4096).  The
+ *        reduction order is fixed (bitwise reproducible).  scratch: pcc_conv_wgrad_scratch_elems floats.
+ *   db = column sums of dY (caller).
+ * ------------------------------------------------------------------------------------- */
+int pcc_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t,
+                             uint32_t* row_mask_t, void* stream);
+int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout);
+int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy, int64_t n_out, int32_t cout,
+                   const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* dw,
+                   float* scratch, int64_t scratch_elems, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Latent-coordinate side channel of file mode.  Replaces ColorModel.gpcc_encode / gpcc_decode
  * (model/model.py:318-395), which shell out to the external MPEG G-PCC binary `tmc3`; this is the
  * build's own lossless octree ("PCO1", NOT G-PCC compatible; container in octree.py).

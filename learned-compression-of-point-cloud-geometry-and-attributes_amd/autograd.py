@@ -1,0 +1,159 @@
+"""Differentiable sparse convolution (training path).
+
+The reference trains through MinkowskiEngine's autograd functions (every ``ME.Minkowski*Convolution*``
+in model/, driven by train.py:194-206).  Here one ``torch.autograd.Function`` wraps the HIP kernels:
+
+    forward   out = bias + sum_k X[nbr[:, k]] @ W[k]                      pcc_conv_fwd
+    backward  dX  = the same kernel over the transposed map with W[k]^T   pcc_kernel_map_transpose + pcc_conv_fwd
+              dW[k] = sum over pairs of X[i]^T dY[j]                      pcc_conv_wgrad
+              db  = column sums of dY
+
+Activations, FiLM and residuals — fused into the convolution's epilogue on the inference path — are
+ordinary torch ops here so that autograd differentiates them.
+"""
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+_THIN_CIN = (1, 2, 4, 8, 16)
+
+
+def _packed(w):
+    """[K, cin, cout] -> MFMA packing (or None for thin cin)"""
+    K, cin, cout = w.shape
+    if cin % 32:
+        return None
+    L = _lib.lib()
+    wp = torch.empty(L.pcc_conv_packed_elems(K, cin, cout), dtype=torch.float32, device=w.device)
+    check(L.pcc_conv_pack_weights(ptr(w), K, cin, cout, ptr(wp), _lib.stream()))
+    return wp
+
+
+def _launch_conv(feats, w, bias, nbr, order, gmask, n_out):
+    L = _lib.lib()
+    K, cin, cout = w.shape
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    check(L.pcc_conv_fwd(ptr(feats), feats.shape[0], cin, ptr(w), ptr(_packed(w)), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
+                         ptr(out), n_out, cout, 0, None, None, _lib.stream()))
+    return out
+
+
+def _forward_map(in_map, out_map, ksize, transposed, cin):
+    """(nbr, order, gmask) of the forward map; execution order when the MFMA kernels will run on it"""
+    if ksize == 1:
+        return None, None, None
+    if cin % 32 == 0:
+        nbr, order, gmask, _ = in_map.ordered_kernel_map(out_map, ksize, transposed)
+        return nbr, order, gmask
+    nbr, _, _ = in_map.kernel_map(out_map, ksize, transposed)
+    return nbr, None, None
+
+
+def _transposed_map(in_map, out_map, ksize, transposed):
+    """kernel map of the backward-data convolution: for input row i and offset k the output row that read i"""
+    from .sparse import ORDER_BLOCK_LOG2
+    key = ("tmap", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)
+    hit = in_map._cache.get(key)
+    if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is in_map)):
+        return hit[1:]
+    L = _lib.lib()
+    nbr, _, _ = in_map.kernel_map(out_map, ksize, transposed)
+    K = nbr.shape[1]
+    n_in, n_out = in_map.n, out_map.n
+    dev = nbr.device
+    nbr_t = torch.empty((n_in, K), dtype=torch.int32, device=dev)
+    mask_t = torch.empty(n_in, dtype=torch.int32, device=dev)
+    check(L.pcc_kernel_map_transpose(ptr(nbr), n_out, K, n_in, ptr(nbr_t), ptr(mask_t), _lib.stream()))
+    order = torch.empty(n_in, dtype=torch.int32, device=dev)
+    nbr_s = torch.empty_like(nbr_t)
+    gmask = torch.empty((n_in + 31) // 32, dtype=torch.int32, device=dev)
+    nbytes = L.pcc_order_scratch_bytes(n_in)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(L.pcc_order_rows_by_mask(ptr(mask_t), ptr(in_map.coords), n_in, ORDER_BLOCK_LOG2, in_map.stride, ptr(nbr_t), K, ptr(order),
+                                   ptr(nbr_s), ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
+    res = (nbr_t, nbr_s, order, gmask)
+    in_map._cache[key] = (None if out_map is in_map else out_map,) + res
+    return res
+
+
+class SparseConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, kernel, bias, in_map, out_map, ksize, transposed, out_channels):
+        feats = feats.contiguous()
+        w = kernel.detach()
+        if w.dim() == 2:
+            w = w.unsqueeze(0)
+        b = None if bias is None else bias.detach().reshape(-1)
+        if out_channels is not None:
+            w = w[:, :, :out_channels]
+            b = None if b is None else b[:out_channels].contiguous()
+        w = w.contiguous()
+        nbr, order, gmask = _forward_map(in_map, out_map, ksize, transposed, feats.shape[1])
+        out = _launch_conv(feats, w, b, nbr, order, gmask, out_map.n)
+        ctx.save_for_backward(feats, w)
+        ctx.meta = (in_map, out_map, ksize, transposed, out_channels, tuple(kernel.shape), bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        feats, w = ctx.saved_tensors
+        in_map, out_map, ksize, transposed, out_channels, kshape, has_bias = ctx.meta
+        dy = dy.contiguous()
+        K, cin, cout = w.shape
+        n_in, n_out = feats.shape[0], dy.shape[0]
+        dev = dy.device
+        d_feats = d_kernel = d_bias = None
+
+        if ctx.needs_input_grad[1]:
+            mfma = cin % 32 == 0 and cout % 32 == 0
+            if ksize == 1:
+                nbr = torch.arange(n_out, dtype=torch.int32, device=dev).unsqueeze(1).contiguous()
+                order = gmask = None
+            elif mfma:
+                nbr, order, gmask, _ = in_map.ordered_kernel_map(out_map, ksize, transposed)
+            else:
+                nbr, _, _ = in_map.kernel_map(out_map, ksize, transposed)
+                order = gmask = None
+            dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
+            ne = L.pcc_conv_wgrad_scratch_elems(K, cin, cout)
+            scratch = torch.empty(ne, dtype=torch.float32, device=dev)
+            check(L.pcc_conv_wgrad(ptr(feats), n_in, cin, ptr(dy), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw), ptr(scratch),
+                                   ne, _lib.stream()))
+            if out_channels is not None:
+                full = torch.zeros((K, cin, kshape[-1]), dtype=torch.float32, device=dev)
+                full[:, :, :out_channels] = dw
+                dw = full
+            d_kernel = dw.reshape(kshape)
+
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=0)
+            if out_channels is not None:
+                full = torch.zeros(kshape[-1], dtype=torch.float32, device=dev)
+                full[:out_channels] = db
+                db = full
+            d_bias = db.reshape(1, -1)
+
+        if ctx.needs_input_grad[0]:
+            wt = w.transpose(1, 2)                                  # [K, cout, cin]
+            g = dy
+            if cout % 32 and cout not in _THIN_CIN:                 # the thin forward kernel takes 1, 2, 4, 8 or 16 input channels
+                pad = next(c for c in _THIN_CIN if c >= cout) - cout
+                g = torch.cat([dy, torch.zeros((n_out, pad), dtype=torch.float32, device=dev)], dim=1).contiguous()
+                wt = torch.cat([wt, torch.zeros((K, pad, cin), dtype=torch.float32, device=dev)], dim=1)
+            wt = wt.contiguous()
+            if ksize == 1:
+                d_feats = _launch_conv(g, wt, None, None, None, None, n_in)
+            else:
+                nbr_t, nbr_s, order_t, gmask_t = _transposed_map(in_map, out_map, ksize, transposed)
+                if g.shape[1] % 32 == 0:
+                    d_feats = _launch_conv(g, wt, None, nbr_s, order_t, gmask_t, n_in)
+                else:
+                    d_feats = _launch_conv(g, wt, None, nbr_t, None, None, n_in)
+        return d_feats, d_kernel, d_bias, None, None, None, None, None
+
+
+def conv_train(x_feats, in_map, out_map, layer, ksize, transposed, out_channels=None):
+    """differentiable out = bias + conv(x) on the HIP kernels"""
+    return SparseConvFn.apply(x_feats, layer.kernel, layer.bias, in_map, out_map, ksize, transposed, out_channels)

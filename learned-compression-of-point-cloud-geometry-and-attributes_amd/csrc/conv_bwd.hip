@@ -1,0 +1,232 @@
+// Backward of the sparse convolution (training path; the reference gets these
+// from MinkowskiEngine's autograd functions behind every ME.Minkowski*Convolution*, train.py:194-206).
+//
+//   dX[i] = sum_k dY[j(i,k)] . W[k]^T   -> pcc_kernel_map_transpose + the forward kernel (pcc_conv_fwd) on
+//                                          the transposed map with transposed weights: same MFMA loop.
+//   dW[k] = sum_{(i,j) in map_k} X[i]^T dY[j]   -> conv_wgrad_kernel below (fp32 MFMA, rows are the GEMM's
+//                                          K dimension), deterministic two-stage reduction.
+//   db    = column sums of dY (caller).
+//
+// wgrad tiling: one workgroup owns kernel offset k, a 128 x 128 block of W[k] and every SPLIT-th group
+// of 32 output rows (execution order of pcc_order_rows_by_mask; groups whose mask lacks k are
+// skipped).  Per group the gathered X rows and the dY rows land in LDS as [chunk][row][32] images by
+// buffer_load ... lds (absent neighbours: out-of-range offset -> zeros) and feed
+// v_mfma_f32_32x32x2_f32 with A = X^T, B = dY: lane (r, h) reads X[row 2s+h][ch r] and dY[row 2s+h][co r] —
+// two 128-B rows per ds_read_b32, all 64 banks once.  Single-buffered: 32 KB of LDS and 64
+// accumulator registers per wave leave room for 4 workgroups per CU, which is what hides the
+// index -> gather -> LDS round trips (no software pipeline).  Partials go to scratch
+// [SPLIT][K][cin][cout]; a second kernel adds them in fixed order (bitwise reproducible).
+// Roofline: MFMA fp32; algorithmic FLOPs = 2 * pairs * cin * cout, like the forward.
+#include "common.h"
+
+namespace pcc {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int WG_SPLIT = 32;
+constexpr uint32_t WG_OOB = 0xFFFFF000u;
+[[maybe_unused]] constexpr uint32_t WG_FLAGS = 0x00020000u;
+
+__global__ __launch_bounds__(256) void map_transpose_kernel(const int32_t* __restrict__ nbr, int64_t n_out, int K,
+                                                            int32_t* __restrict__ nbr_t, uint32_t* __restrict__ mask_t) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_out * K) return;
+    const int i = nbr[e];
+    if (i < 0) return;
+    const int k = (int)(e % K);
+    nbr_t[(int64_t)i * K + k] = (int32_t)(e / K);
+    atomicOr(&mask_t[i], 1u << k);
+}
+
+struct WgradArgs {
+    const float* fin;
+    const float* dy;
+    const int32_t* nbr;      // [n_out, K] in execution order
+    const int32_t* order;    // [n_out] execution position -> row of dy, or null
+    const uint32_t* gmask;   // [ceil(n_out / 32)] or null
+    float* partial;          // [WG_SPLIT, K, cin, cout]
+    int64_t n_in, n_out;
+    int cin, cout, K;
+};
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                // [4 chunks][32 rows][32 ch]
+    float* Bs = smem + 4 * 1024;     // [4 chunks][32 rows][32 co]
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    const int k = blockIdx.x / WG_SPLIT, s = blockIdx.x % WG_SPLIT;
+    const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
+    const int cbi = min(4, (a.cin - cin0) / 32), cbo = min(4, (a.cout - cout0) / 32);     // chunks present in this block
+    const int wm = wave_u >> 1, wn = wave_u & 1;                                          // 64 x 64 sub-block of the wave
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+
+    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 4), WG_FLAGS);
+    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(uint32_t)(a.n_out * a.cout * 4), WG_FLAGS);
+    const int64_t ng = (a.n_out + 31) >> 5;
+    const int slot = lane & 7, rsub = lane >> 3;          // DMA role: 8 lanes per row, 8 rows per instruction
+    const bool live_m[2] = {2 * wm < cbi, 2 * wm + 1 < cbi};
+    const bool live_n[2] = {2 * wn < cbo, 2 * wn + 1 < cbo};
+
+    for (int64_t g = s; g < ng; g += WG_SPLIT) {
+        const uint32_t gm = __builtin_amdgcn_readfirstlane(a.gmask ? a.gmask[g] : 0xffffffffu);
+        if (!((gm >> k) & 1u)) continue;                  // wave-uniform: no row of the group has this offset
+        // wave w stages chunk w of both operands: 4 instructions x 8 rows each
+        uint32_t voa[4], vob[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t pos = g * 32 + 8 * i + rsub;
+            const bool ok = pos < a.n_out;
+            const int idx = ok ? a.nbr[pos * a.K + k] : -1;
+            const int64_t row = ok ? (a.order ? a.order[pos] : pos) : 0;
+            voa[i] = (idx >= 0 && wave_u < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 4) + (uint32_t)((cin0 + wave_u * 32) * 4 + slot * 16) : WG_OOB;
+            vob[i] = (ok && wave_u < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 4) + (uint32_t)((cout0 + wave_u * 32) * 4 + slot * 16) : WG_OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + wave_u * 1024 + i * 256), 16, voa[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Bs + wave_u * 1024 + i * 256), 16, vob[i], 0, 0, 0);
+        }
+        __syncthreads();
+        const float* Ab = As + (2 * wm) * 1024 + h * 32 + r;
+        const float* Bb = Bs + (2 * wn) * 1024 + h * 32 + r;
+#pragma unroll 4
+        for (int kp = 0; kp < 16; ++kp) {
+            float av[2], bv[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) av[m] = Ab[m * 1024 + kp * 64];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) bv[n] = Bb[n * 1024 + kp * 64];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // D[row = (reg & 3) + 8 (reg >> 2) + 4 h][col = r] of each 32 x 32 tile: row = input channel, col = output channel
+    float* P = a.partial + ((int64_t)s * a.K + k) * a.cin * a.cout;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (!live_m[m]) continue;
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            if (!live_n[n]) continue;
+            const int co = cout0 + (2 * wn + n) * 32 + r;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int ci = cin0 + (2 * wm + m) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                P[(int64_t)ci * a.cout + co] = acc[m][n][reg];
+            }
+        }
+    }
+#endif
+}
+
+// thin shapes (cin or cout not a multiple of 32: q-map branches, input layer, narrow heads): cin * cout <= 4096.
+// One workgroup per (offset, split); a thread owns (ci, co) pairs and walks the split's rows.
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a) {
+    const int k = blockIdx.x / WG_SPLIT, s = blockIdx.x % WG_SPLIT;
+    const int pairs = a.cin * a.cout;
+    float acc[16];
+    int ci[16], co[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        acc[q] = 0.0f;
+        const int e = min(threadIdx.x + 256 * q, pairs - 1);
+        ci[q] = e / a.cout;
+        co[q] = e - ci[q] * a.cout;
+    }
+    const int64_t per = (a.n_out + WG_SPLIT - 1) / WG_SPLIT;
+    const int64_t lo = s * per, hi = min(a.n_out, lo + per);
+    for (int64_t pos = lo; pos < hi; ++pos) {
+        const int idx = a.nbr[pos * a.K + k];
+        if (idx < 0) continue;                                          // block-uniform
+        const int64_t row = a.order ? a.order[pos] : pos;
+        const float* x = a.fin + (int64_t)idx * a.cin;
+        const float* y = a.dy + row * a.cout;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            if (256 * q < pairs) acc[q] = fmaf(x[ci[q]], y[co[q]], acc[q]);
+        }
+    }
+    float* P = a.partial + ((int64_t)s * a.K + k) * pairs;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int e = threadIdx.x + 256 * q;
+        if (e < pairs) P[e] = acc[q];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int64_t elems, float* __restrict__ dw) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    float sum = 0.0f;
+    for (int s = 0; s < WG_SPLIT; ++s) sum += partial[(int64_t)s * elems + e];      // fixed order
+    dw[e] = sum;
+}
+
+}  // namespace pcc
+
+using namespace pcc;
+
+extern "C" {
+
+int pcc_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64_t n_in, int32_t* nbr_t, uint32_t* row_mask_t,
+                             void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_kernel_map_transpose: K out of range");
+    PCC_REQUIRE(n_in < (1ll << 31) && n_out < (1ll << 31), "pcc_kernel_map_transpose: too many rows");
+    hipStream_t st = as_stream(stream);
+    if (n_in > 0) {
+        PCC_CHECK_HIP(hipMemsetAsync(nbr_t, 0xFF, (size_t)n_in * K * sizeof(int32_t), st));
+        PCC_CHECK_HIP(hipMemsetAsync(row_mask_t, 0, (size_t)n_in * sizeof(uint32_t), st));
+    }
+    if (n_out <= 0 || n_in <= 0) return PCC_OK;
+    hipLaunchKernelGGL(map_transpose_kernel, dim3(blocks_for(n_out * K, 256)), dim3(256), 0, st, nbr, n_out, K, nbr_t, row_mask_t);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout) { return (int64_t)WG_SPLIT * K * cin * cout; }
+
+int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy, int64_t n_out, int32_t cout, const int32_t* nbr,
+                   const int32_t* order, const uint32_t* group_mask32, int32_t K, float* dw, float* scratch, int64_t scratch_elems,
+                   void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27 && cin >= 1 && cout >= 1, "pcc_conv_wgrad: bad shape");
+    PCC_REQUIRE(nbr != nullptr, "pcc_conv_wgrad: neighbour table required (kernel_size 1: pass the identity map)");
+    PCC_REQUIRE(scratch_elems >= pcc_conv_wgrad_scratch_elems(K, cin, cout), "pcc_conv_wgrad: scratch too small");
+    hipStream_t st = as_stream(stream);
+    const int64_t elems = (int64_t)K * cin * cout;
+    if (n_out <= 0) {
+        PCC_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), st));
+        return PCC_OK;
+    }
+    WgradArgs a;
+    a.fin = fin; a.dy = dy; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.partial = scratch;
+    a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.K = K;
+    if (cin % 32 == 0 && cout % 32 == 0) {
+        PCC_REQUIRE((uint64_t)n_in * cin * 4 <= WG_OOB && (uint64_t)n_out * cout * 4 <= WG_OOB,
+                    "pcc_conv_wgrad: operands of 4 GiB and more are not supported yet");
+        const dim3 grid((unsigned)(K * WG_SPLIT), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
+        hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 8 * 1024 * sizeof(float), st, a);
+    } else {
+        PCC_REQUIRE((int64_t)cin * cout <= 4096, "pcc_conv_wgrad: thin path handles cin * cout <= 4096 (got %d x %d)", cin, cout);
+        hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3((unsigned)(K * WG_SPLIT)), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, dw);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,113 @@
+"""Training path, operator level: gradients of the HIP convolution against
+torch autograd through the CPU oracle's convolution (the reference differentiates through
+MinkowskiEngine, train.py:194-206)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import nn as on
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def shell(grid=36, radius=13.0, thick=0.9):
+    g = np.stack(np.meshgrid(*[np.arange(grid)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    keep = np.abs(np.linalg.norm(g - (grid - 1) / 2, axis=1) - radius) < thick
+    return np.concatenate([np.zeros((int(keep.sum()), 1), np.int32), g[keep].astype(np.int32)], axis=1)
+
+
+def close(a, b, tol=2e-4):
+    scale = float(b.abs().max()) + 1e-12
+    return float((a - b).abs().max()) <= tol * scale
+
+
+SHAPES = [(128, 128, 3), (64, 64, 3), (64, 128, 3), (128, 256, 3), (192, 64, 3), (4, 64, 3), (2, 2, 3), (2, 128, 3), (16, 16, 1),
+          (128, 128, 1), (64, 3, 3), (128, 2, 3), (32, 3, 3)]
+
+
+@pytest.mark.parametrize("cin,cout,ksize", SHAPES)
+def test_conv_gradients_match_autograd(pcc, cin, cout, ksize):
+    torch.manual_seed(cin * 7 + cout)
+    c = shell()
+    n = c.shape[0]
+    layer = pcc.MinkowskiConvolution(cin, cout, kernel_size=ksize, stride=1, bias=True, dimension=3).to(DEV)
+    with torch.no_grad():
+        layer.kernel.normal_(0, 1.0 / np.sqrt(cin * 10))
+        layer.bias.normal_(0, 0.1)
+    F = torch.randn(n, cin)
+    G = torch.randn(n, cout)
+    x = F.to(DEV).requires_grad_(True)
+    out = layer(pcc.SparseTensor(x, coordinate_map=pcc.CoordMap(torch.from_numpy(c).to(DEV), 1))).F
+    (out * G.to(DEV)).sum().backward()
+    Fo = F.clone().requires_grad_(True)
+    Wo = layer.kernel.detach().cpu().clone().requires_grad_(True)
+    bo = layer.bias.detach().cpu().clone().requires_grad_(True)
+    if ksize == 1:
+        ref = Fo @ Wo + bo
+    else:
+        ref = on._apply_conv(Fo, Wo, bo, oc.kernel_map(c, c, ksize, 1), n)
+    (ref * G).sum().backward()
+    assert close(out.detach().cpu(), ref.detach())
+    assert close(x.grad.cpu(), Fo.grad), "dX"
+    assert close(layer.kernel.grad.cpu(), Wo.grad), "dW"
+    assert close(layer.bias.grad.cpu(), bo.grad), "db"
+
+
+@pytest.mark.parametrize("kind", ["down", "up3", "up2"])
+def test_strided_and_transposed_gradients(pcc, kind):
+    torch.manual_seed(3)
+    c = shell() * np.array([1, 2, 2, 2], dtype=np.int32)
+    n = c.shape[0]
+    cin, cout = 64, 128
+    if kind == "down":
+        layer = pcc.MinkowskiConvolution(cin, cout, kernel_size=3, stride=2, bias=True, dimension=3).to(DEV)
+    else:
+        layer = pcc.MinkowskiGenerativeConvolutionTranspose(cin, cout, kernel_size=int(kind[-1]), stride=2, bias=True, dimension=3).to(DEV)
+    F = torch.randn(n, cin)
+    x = F.to(DEV).requires_grad_(True)
+    got = layer(pcc.SparseTensor(x, coordinate_map=pcc.CoordMap(torch.from_numpy(c).to(DEV), 2)))
+    Fo = F.clone().requires_grad_(True)
+    Wo = layer.kernel.detach().cpu().clone().requires_grad_(True)
+    bo = layer.bias.detach().cpu().clone().requires_grad_(True)
+    xo = on.SparseTensor(c, Fo, 2)
+    want = on.conv(xo, Wo, bo, 3, 2) if kind == "down" else on.conv_transpose_generative(xo, Wo, bo, int(kind[-1]))
+    idx = torch.from_numpy(oc.lookup(want.C, got.C.cpu().numpy())).long()          # oracle row of every product row
+    G = torch.randn(want.F.shape)
+    (got.F * G[idx].to(DEV)).sum().backward()
+    (want.F * G).sum().backward()
+    assert close(got.F.detach().cpu(), want.F.detach()[idx])
+    assert close(x.grad.cpu(), Fo.grad), "dX"
+    assert close(layer.kernel.grad.cpu(), Wo.grad), "dW"
+    assert close(layer.bias.grad.cpu(), bo.grad), "db"
+
+
+def test_fused_epilogue_terms_and_channel_slice_are_differentiated(pcc):
+    """FiLM, activation and residual become torch ops on the training path; the occupancy head's
+    channel-0-only evaluation (blocks.py:142) must leave zero gradient in the unused channels"""
+    from pcc_amd import sparse as sp
+    torch.manual_seed(5)
+    c = shell()
+    n = c.shape[0]
+    layer = pcc.MinkowskiConvolution(64, 64, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
+    F, film, res = torch.randn(n, 64), torch.randn(n, 128), torch.randn(n, 64)
+    x = F.to(DEV).requires_grad_(True)
+    fm = film.to(DEV).requires_grad_(True)
+    m = pcc.CoordMap(torch.from_numpy(c).to(DEV), 1)
+    out = layer(pcc.SparseTensor(x, coordinate_map=m), act=sp.ACT_LRELU, film=fm, residual=res.to(DEV)).F
+    out.square().sum().backward()
+    Fo, fo = F.clone().requires_grad_(True), film.clone().requires_grad_(True)
+    Wo = layer.kernel.detach().cpu().clone().requires_grad_(True)
+    bo = layer.bias.detach().cpu().clone().requires_grad_(True)
+    base = on._apply_conv(Fo, Wo, bo, oc.kernel_map(c, c, 3, 1), n)
+    ref = torch.nn.functional.leaky_relu(base * fo[:, :64] + fo[:, 64:], 0.01) + res
+    ref.square().sum().backward()
+    assert close(x.grad.cpu(), Fo.grad) and close(fm.grad.cpu(), fo.grad) and close(layer.kernel.grad.cpu(), Wo.grad)
+    layer.zero_grad()
+    out1 = layer(pcc.SparseTensor(F.to(DEV), coordinate_map=m), out_channels=1).F
+    assert out1.shape == (n, 1)
+    out1.sum().backward()
+    g = layer.kernel.grad
+    assert float(g[:, :, 1:].abs().max()) == 0.0 and float(g[:, :, 0].abs().max()) > 0
+    assert float(layer.bias.grad[0, 1:].abs().max()) == 0.0
