@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int k = blockIdx.x / WG_SPLIT, s = blockIdx.x % WG_SPLIT;
     const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
     const int cbi = min(4, (a.cin - cin0) / 32), cbo = min(4, (a.cout - cout0) / 32);     // chunks present in this block
-    const int wm = wave_u >> 1, wn = wave_u & 1;                                          // 64 x 64 sub-block of the wave
+    // Blocks of at most 64 x 64 (64-channel layers) would leave three of the four waves without a tile:
+    // there the waves split the group's 32 ROWS instead (8 each) and write one partial per wave.
+    const bool rowsplit = a.cin <= 64 && a.cout <= 64;       // a property of the layer, not of the block (host agrees)
+    const int wm = rowsplit ? 0 : wave_u >> 1, wn = rowsplit ? 0 : wave_u & 1;           // 64 x 64 sub-block of the wave
+    const int kp0 = rowsplit ? 4 * wave_u : 0, kp1 = rowsplit ? 4 * wave_u + 4 : 16;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -100,8 +104,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
         __syncthreads();
         const float* Ab = As + (2 * wm) * 1024 + h * 32 + r;
         const float* Bb = Bs + (2 * wn) * 1024 + h * 32 + r;
-#pragma unroll 4
-        for (int kp = 0; kp < 16; ++kp) {
+        for (int kp = kp0; kp < kp1; ++kp) {
             float av[2], bv[2];
 #pragma unroll
             for (int m = 0; m < 2; ++m) av[m] = Ab[m * 1024 + kp * 64];
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     }
 
     // D[row = (reg & 3) + 8 (reg >> 2) + 4 h][col = r] of each 32 x 32 tile: row = input channel, col = output channel
-    float* P = a.partial + ((int64_t)s * a.K + k) * a.cin * a.cout;
+    float* P = a.partial + ((int64_t)(rowsplit ? s * 4 + wave_u : s) * a.K + k) * a.cin * a.cout;
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
         if (!live_m[m]) continue;
@@ -169,11 +172,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a)
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int64_t elems, float* __restrict__ dw) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int64_t elems, int nsplit,
+                                                           float* __restrict__ dw) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= elems) return;
     float sum = 0.0f;
-    for (int s = 0; s < WG_SPLIT; ++s) sum += partial[(int64_t)s * elems + e];      // fixed order
+    for (int s = 0; s < nsplit; ++s) sum += partial[(int64_t)s * elems + e];        // fixed order
     dw[e] = sum;
 }
 
@@ -198,7 +202,11 @@ int pcc_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64
     return PCC_OK;
 }
 
-int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout) { return (int64_t)WG_SPLIT * K * cin * cout; }
+static inline bool wgrad_rowsplit(int cin, int cout) { return cin % 32 == 0 && cout % 32 == 0 && cin <= 64 && cout <= 64; }
+
+int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout) {
+    return (int64_t)WG_SPLIT * (wgrad_rowsplit(cin, cout) ? 4 : 1) * K * cin * cout;
+}
 
 int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy, int64_t n_out, int32_t cout, const int32_t* nbr,
                    const int32_t* order, const uint32_t* group_mask32, int32_t K, float* dw, float* scratch, int64_t scratch_elems,
@@ -224,7 +232,8 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
         PCC_REQUIRE((int64_t)cin * cout <= 4096, "pcc_conv_wgrad: thin path handles cin * cout <= 4096 (got %d x %d)", cin, cout);
         hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3((unsigned)(K * WG_SPLIT)), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, dw);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems,
+                       WG_SPLIT * (wgrad_rowsplit(cin, cout) ? 4 : 1), dw);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -25,12 +25,45 @@ def get_scale_table(minimum=SCALES_MIN, maximum=SCALES_MAX, levels=SCALES_LEVELS
     return torch.exp(torch.linspace(math.log(minimum), math.log(maximum), levels))
 
 
+class _LowerBoundFn(torch.autograd.Function):
+    """max(x, bound) whose gradient also flows where x < bound if it pushes x up (compressai.ops.LowerBound)."""
+
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x, bound)
+        return torch.max(x, bound)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, bound = ctx.saved_tensors
+        keep = (x >= bound) | (grad < 0)
+        return keep.to(grad.dtype) * grad, None
+
+
 class _LowerBound(nn.Module):
-    """Buffer holder matching compressai.ops.LowerBound's state_dict entry."""
+    """compressai.ops.LowerBound (same state_dict entry)."""
 
     def __init__(self, bound):
         super().__init__()
         self.register_buffer("bound", torch.tensor([float(bound)]))
+
+    def forward(self, x):
+        return _LowerBoundFn.apply(x, self.bound.to(x.device))
+
+
+# Training-mode quantisation adds U(-0.5, 0.5) noise (compressai EntropyModel.quantize, mode "noise").  Tests
+# replace the source to feed the CPU oracle the same draws: a callable (shape, coords) -> CPU float tensor,
+# where coords are the int32 [N, 4] coordinates of the tensor's points (NOISE_ROWS, set by the caller of the
+# entropy model) — row order differs between implementations, coordinates do not.
+NOISE_SOURCE = None
+NOISE_ROWS = None
+
+
+def _uniform_noise(like):
+    if NOISE_SOURCE is not None:
+        rows = None if NOISE_ROWS is None else NOISE_ROWS.detach().cpu().numpy()
+        return NOISE_SOURCE(tuple(like.shape), rows).to(like.device, like.dtype)
+    return torch.empty_like(like).uniform_(-0.5, 0.5)
 
 
 def _pmf_to_cdf(pmf, tail, pmf_length, max_length):
@@ -240,10 +273,23 @@ class EntropyBottleneck(_EntropyModelBase):
                                            _lib.stream()))
         return lik
 
+    def _likelihood_train(self, v):
+        """differentiable likelihood of v [C, 1, N] (compressai EntropyBottleneck._likelihood); elementwise
+        torch ops: the training path needs gradients into the density parameters"""
+        params = self._density_params()
+        lower = self._logits_cumulative(params, v - 0.5)
+        upper = self._logits_cumulative(params, v + 0.5)
+        sign = -torch.sign(lower + upper).detach()
+        return torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+
     def forward(self, x, training=None):
-        """x: (1, C, N) as in the reference (``z.F.t().unsqueeze(0)``); eval mode only."""
+        """x: (1, C, N) as in the reference (``z.F.t().unsqueeze(0)``) -> (x_hat, likelihoods), both (1, C, N).
+        Training mode: additive uniform noise instead of rounding, likelihoods with gradients."""
         if self.training if training is None else training:
-            raise NotImplementedError("training-mode (noise) quantisation is outside this round's scope (SURVEY §8f)")
+            v = x.permute(1, 0, 2)                                   # [C, 1, N]
+            v = v + _uniform_noise(v)
+            lik = self.likelihood_lower_bound(self._likelihood_train(v))
+            return v.permute(1, 0, 2), lik.permute(1, 0, 2)
         feats = x[0].t().contiguous()
         _, zhat = self.quantize_features(feats, want_symbols=False)
         lik = self.likelihood_features(zhat)
@@ -395,7 +441,14 @@ class GaussianConditional(_EntropyModelBase):
 
     def forward(self, inputs, scales, means=None, training=None):
         if self.training if training is None else training:
-            raise NotImplementedError("training-mode (noise) quantisation is outside this round's scope (SURVEY §8f)")
+            # compressai GaussianConditional.forward, mode "noise": y + U(-.5,.5); likelihood of the noisy value
+            outputs = inputs + _uniform_noise(inputs)
+            values = outputs if means is None else outputs - means
+            s = self.lower_bound_scale(scales)
+            values = torch.abs(values)
+            Phi = lambda t: 0.5 * torch.erfc(-(2 ** -0.5) * t)
+            lik = Phi((0.5 - values) / s) - Phi((-0.5 - values) / s)
+            return outputs, self.likelihood_lower_bound(lik)
         means = torch.zeros_like(inputs) if means is None else means
         params = torch.cat([scales[0].t(), means[0].t()], dim=1).contiguous()
         yhat, lik = self.forward_features(inputs[0].t().contiguous(), params)

@@ -69,8 +69,20 @@ class MeanScaleHyperprior_Map(nn.Module):
         return self.h_s(z_hat, last_out_map=y_map).F
 
     def forward(self, y):
-        """Eval-mode forward (entropy_models.py:309-337): -> y_hat, Q_hat, (L_y, L_z)."""
+        """entropy_models.py:309-337: -> y_hat, Q_hat, (L_y, L_z).  Eval: rounding + HIP likelihood kernels;
+        training: additive noise and differentiable likelihoods (compressai's "noise" mode)."""
         z = self.h_a(y)
+        if self.training:
+            from . import entropy as _e
+            _e.NOISE_ROWS = z.C
+            z_hat_f, z_lik = self.entropy_bottleneck(z.F.t().unsqueeze(0))
+            z_hat = SparseTensor(z_hat_f[0].t().contiguous(), coordinate_map=z.map)
+            params = self._params_at(z_hat, y.map)
+            Q_hat = self.h_q(z_hat)
+            scales, means = params.chunk(2, dim=1)
+            _e.NOISE_ROWS = y.C
+            y_hat_f, y_lik = self.gaussian_conditional(y.F.t().unsqueeze(0), scales.t().unsqueeze(0), means=means.t().unsqueeze(0))
+            return SparseTensor(y_hat_f[0].t().contiguous(), coordinate_map=y.map), Q_hat, (y_lik, z_lik)
         z_in = z.F.t().unsqueeze(0)
         z_hat_f, z_lik = self.entropy_bottleneck(z_in)
         z_hat = SparseTensor(z_hat_f[0].t().contiguous(), coordinate_map=z.map)

@@ -45,11 +45,8 @@ class ColorModel(nn.Module):
     def device(self):
         return self.g_s.down_conv.kernel.device
 
-    # -- model/model.py:51-93 (eval mode) -----------------------------------------------------------
+    # -- model/model.py:51-93 (eval: rounding; train: noise quantisation, autograd through the HIP kernels) ----
     def forward(self, x, Q, Lambda=None):
-        if self.training:
-            raise NotImplementedError("training forward/backward is the next scope row (SURVEY.md §8f); "
-                                      "call .eval() for the inference forward")
         coords = SparseTensor(coordinate_map=x.map)
         ones = torch.ones((x.map.n, 1), dtype=torch.float32, device=x.device)
         x = SparseTensor(torch.cat([ones, x.F], dim=1), coordinate_map=x.map)

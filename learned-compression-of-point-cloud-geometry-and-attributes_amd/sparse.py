@@ -227,7 +227,18 @@ class SparseTensor:
 # ---------------------------------------------------------------------------------------------
 # functional operators
 # ---------------------------------------------------------------------------------------------
+def _tracked(*tensors):
+    """True when autograd must see the operation (training path): plain torch indexing ops then stand in for
+    the HIP row movers — same values, differentiable"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
+
+
 def gather_rows(src, idx, out=None, accumulate=False):
+    """out[r] (+)= src[idx[r]] (zero rows where idx < 0).  Returns the result: callers must use the return
+    value (on the training path a new tensor is returned instead of writing into ``out``)."""
+    if _tracked(src, out):
+        sel = src.index_select(0, idx.clamp(min=0).long()) * (idx >= 0).unsqueeze(1).to(src.dtype)
+        return out + sel if (accumulate and out is not None) else sel
     n = idx.shape[0]
     c = src.shape[1]
     if out is None:
@@ -237,6 +248,9 @@ def gather_rows(src, idx, out=None, accumulate=False):
 
 
 def scatter_rows(src, idx, n_out):
+    if _tracked(src):
+        ok = idx >= 0
+        return torch.zeros((n_out, src.shape[1]), dtype=src.dtype, device=src.device).index_add(0, idx[ok].long(), src[ok])
     out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
     check(_lib.lib().pcc_scatter_rows(ptr(src), src.shape[1], ptr(idx), idx.shape[0], ptr(out), _lib.stream()))
     return out
@@ -244,6 +258,9 @@ def scatter_rows(src, idx, n_out):
 
 def compact_rows(mask, coords=None, feats=None, want_index=False):
     """Order-preserving compaction (ME.MinkowskiPruning).  Returns (coords, feats, new_index, n)."""
+    if _tracked(feats):
+        coords_k, _, new_index, m = compact_rows(mask, coords, None, want_index)
+        return coords_k, feats[mask.bool()], new_index, m
     L = _lib.lib()
     n = mask.shape[0]
     dev = mask.device

@@ -130,8 +130,7 @@ class SparseSynthesisTransform(nn.Module):
             if Q.map is x.map:
                 Q = SparseTensor(Q.F + Q_plus.F, coordinate_map=Q.map)
             else:
-                feats = Q.F.clone()
-                sp.gather_rows(Q_plus.F, Q_plus.map.lookup(Q.C), out=feats, accumulate=True)
+                feats = sp.gather_rows(Q_plus.F, Q_plus.map.lookup(Q.C), out=Q.F.clone(), accumulate=True)
                 Q = SparseTensor(feats, coordinate_map=Q.map)
 
         x = self.pre_conv(x)

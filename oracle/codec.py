@@ -44,7 +44,7 @@ def topk_mask(pred, k):
     torch.topk leaves ties unspecified; the oracle (and the HIP path) break
     exact ties by ascending canonical coordinate key.
     """
-    logits = pred.F[:, 0].numpy()
+    logits = pred.F[:, 0].detach().numpy()
     keys = oc.pack(pred.C)
     b = pred.C[:, 0]
     mask = np.zeros(logits.shape[0], dtype=bool)

@@ -257,7 +257,8 @@ h = hashlib.sha256()
 for cin, cout in [(128, 128), (64, 64), (96, 32), (128, 256)]:
     layer = pcc_amd.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).to("cuda:0")
     F = torch.randn(c.shape[0], cin, device="cuda:0")
-    out = layer(pcc_amd.SparseTensor(F, coordinate_map=pcc_amd.CoordMap(torch.from_numpy(c).to("cuda:0"), 1))).F
+    with torch.no_grad():
+        out = layer(pcc_amd.SparseTensor(F, coordinate_map=pcc_amd.CoordMap(torch.from_numpy(c).to("cuda:0"), 1))).F
     h.update(out.cpu().numpy().tobytes())
 print("DIGEST", h.hexdigest())
 """

@@ -1,0 +1,127 @@
+"""Training path, model level: ColorModel.forward in training mode + the
+configured losses, differentiated through the HIP kernels, against the CPU oracle differentiated by
+torch autograd with the same noise draws (reference: train.py:171-221, model/model.py:51-93,
+loss.py:67-195)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import train as ot
+from oracle.codec import Codec
+from oracle.nn import SparseTensor as OSparseTensor
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def coord_noise(shape, coords):
+    """U(-0.5, 0.5)-like noise that is a function of (channel, coordinate), not of the row position"""
+    c = np.asarray(coords, dtype=np.float64)
+    n = c.shape[0]
+    ch = shape[0] if shape[0] != 1 else shape[1]
+    phase = c[:, 1] * 12.9898 + c[:, 2] * 78.233 + c[:, 3] * 37.719
+    val = np.sin(phase[None, :] * (1.0 + 0.37 * np.arange(ch)[:, None])) * 43758.5453
+    val = (val - np.floor(val) - 0.5).astype(np.float32)            # [ch, n]
+    assert val.shape == (ch, n)
+    return torch.from_numpy(val.reshape(shape))
+
+
+def _setup(pcc):
+    from pcc_amd import synthetic as syn
+    model = syn.make_model(seed=0, device=DEV)
+    pts = syn.sphere_shell(**syn.CONFIG1)
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.3, 0.7)
+    qf = qf.copy()
+    qf[:, 0] = 0.2 + 0.6 * (pts[:, 0] - pts[:, 0].min()) / (pts[:, 0].max() - pts[:, 0].min())     # a gradient map: pooling matters
+    lam = np.stack([2 ** (qf[:, 0] * 6) + 24, 2 ** (qf[:, 1] * 7) + 99], axis=1).astype(np.float32)
+    return model, pts, qc, qf, lam
+
+
+def test_training_step_matches_oracle_autograd(pcc):
+    from pcc_amd import entropy as pe
+    from pcc_amd.loss import OURS_LOSS, Loss
+    model, pts, qc, qf, lam = _setup(pcc)
+    model.train()
+    coords = torch.from_numpy(qc).to(DEV)
+    inp = pcc.SparseTensor(coordinates=coords, features=torch.from_numpy(pts[:, 3:]).to(DEV), device=DEV)
+    Q = pcc.SparseTensor(torch.from_numpy(qf).to(DEV), coordinate_map=inp.map)
+    Lam = pcc.SparseTensor(torch.from_numpy(lam).to(DEV), coordinate_map=inp.map)
+    pe.NOISE_SOURCE = coord_noise
+    try:
+        out = model(inp, Q, Lam)
+    finally:
+        pe.NOISE_SOURCE = None
+    total, parts = Loss(OURS_LOSS)(inp, out)
+    total.backward()
+
+    sd = ot.leaf_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    codec = Codec(sd)
+    codec.sd, codec.p = sd, type(codec.p)(sd)
+    codec.eb = type(codec.eb)(codec.p.sub("entropy_model").sub("entropy_bottleneck"))
+    o_out = ot.forward_train(codec, qc, pts[:, 3:], qc, qf, coord_noise)
+    o_total, o_parts = ot.losses(qc, pts[:, 3:], o_out, OSparseTensor(qc, torch.from_numpy(lam), 1))
+    o_total.backward()
+
+    for key in o_parts:
+        assert float(parts[key].detach()) == pytest.approx(float(o_parts[key].detach()), rel=2e-4), key
+    assert out["prediction"].F.shape == (pts.shape[0], 3)
+    checked = 0
+    named = dict(model.named_parameters())
+    worst = (0.0, None)
+    for name, leaf in sd.items():
+        if leaf.grad is None or name not in named:
+            continue
+        g = named[name].grad
+        assert g is not None, name
+        ref = leaf.grad
+        scale = float(ref.abs().max())
+        if scale == 0.0:
+            assert float(g.abs().max()) == 0.0, name
+            continue
+        err = float((g.cpu() - ref).abs().max()) / scale
+        worst = max(worst, (err, name))
+        checked += 1
+    assert checked > 150, checked
+    assert worst[0] < 5e-3, worst          # fp32 sums in different orders through ~60 layers
+
+
+def test_training_mode_draws_fresh_noise_and_eval_is_unchanged(pcc):
+    model, pts, qc, qf, lam = _setup(pcc)
+    coords = torch.from_numpy(qc).to(DEV)
+    inp = pcc.SparseTensor(coordinates=coords, features=torch.from_numpy(pts[:, 3:]).to(DEV), device=DEV)
+    Q = pcc.SparseTensor(torch.from_numpy(qf).to(DEV), coordinate_map=inp.map)
+    model.train()
+    a = model(inp, Q, None)["likelihoods"]["y"]
+    b = model(inp, Q, None)["likelihoods"]["y"]
+    assert not torch.equal(a, b)
+    model.eval()
+    with torch.no_grad():
+        c = model(inp, Q, None)["likelihoods"]["y"]
+        d = model(inp, Q, None)["likelihoods"]["y"]
+    assert torch.equal(c, d)
+
+
+def test_optimizer_step_reduces_the_loss(pcc):
+    """three Adam steps on one frame (train.py:194-206 without the data loader)"""
+    from pcc_amd.loss import OURS_LOSS, Loss
+    model, pts, qc, qf, lam = _setup(pcc)
+    model.train()
+    coords = torch.from_numpy(qc).to(DEV)
+    inp = pcc.SparseTensor(coordinates=coords, features=torch.from_numpy(pts[:, 3:]).to(DEV), device=DEV)
+    Q = pcc.SparseTensor(torch.from_numpy(qf).to(DEV), coordinate_map=inp.map)
+    Lam = pcc.SparseTensor(torch.from_numpy(lam).to(DEV), coordinate_map=inp.map)
+    params = [p for n, p in model.named_parameters() if not n.endswith(".quantiles")]      # train.py:63-64
+    opt = torch.optim.Adam(params, lr=1e-4)
+    loss_fn = Loss(OURS_LOSS)
+    values = []
+    for _ in range(4):
+        opt.zero_grad()
+        total, _ = loss_fn(inp, model(inp, Q, Lam))
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(params, 1.0)
+        opt.step()
+        values.append(float(total.detach()))
+    assert all(np.isfinite(values)) and values[-1] < values[0]
+    aux = model.aux_loss()
+    aux.backward()
+    assert model.entropy_model.entropy_bottleneck.quantiles.grad is not None
