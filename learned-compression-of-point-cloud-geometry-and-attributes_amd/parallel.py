@@ -108,3 +108,100 @@ def decompress_blocks(model, units):
     out = [model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
            for _, strings, shape, k, coords in units]
     return torch.cat(out, dim=0)
+
+
+# ---------------------------------------------------------------------------------------------
+# data-parallel training (BASELINE config 5; the reference trains on one GPU, train.py:171-221)
+# ---------------------------------------------------------------------------------------------
+class GradBucketReducer:
+    """Gradient averaging across ranks, overlapped with backward.
+
+    Parameters are laid out (in reverse registration order — roughly the order backward produces their
+    gradients) into flat fp32 buckets of ``bucket_bytes``; a bucket is all-reduced asynchronously as soon
+    as the last of its gradients has been accumulated (post-accumulate-grad hooks), so the collectives
+    of the late layers run under the backward of the early ones.  xGMI is point-to-point: a ring
+    all-reduce moves 2 (W-1)/W of a bucket over one ~150 GB/s link per hop, so buckets are sized in
+    tens of MB — large enough to be bandwidth-bound, small enough to leave backward to hide behind
+    (31.5 M parameters = 126 MB = 4 buckets).  Parameters that received no gradient this step (the
+    codec has structurally unused ones: gdn, conv_layers, q_up_i.conv_2) contribute zeros, so every
+    rank issues the same collectives whatever its data.
+
+    usage:  red = GradBucketReducer(model.parameters());  loss.backward();  red.finish();  opt.step()
+    """
+
+    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []          # (flat tensor, [(param, offset, numel)])
+        cur, cur_elems = [], 0
+        limit = max(1, bucket_bytes // 4)
+        for p in reversed(self.params):
+            if cur and cur_elems + p.numel() > limit:
+                self._close(cur, cur_elems)
+                cur, cur_elems = [], 0
+            cur.append(p)
+            cur_elems += p.numel()
+        if cur:
+            self._close(cur, cur_elems)
+        self._pending = [0] * len(self.buckets)
+        self._works = [None] * len(self.buckets)
+        self._where = {}
+        for b, (_, items) in enumerate(self.buckets):
+            for p, _, _ in items:
+                self._where[p] = b
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        self._arm()
+
+    def _close(self, plist, elems):
+        flat = torch.zeros(elems, dtype=torch.float32, device=plist[0].device)
+        items, off = [], 0
+        for p in plist:
+            items.append((p, off, p.numel()))
+            off += p.numel()
+        self.buckets.append((flat, items))
+
+    def _arm(self):
+        for b, (_, items) in enumerate(self.buckets):
+            self._pending[b] = len(items)
+            self._works[b] = None
+        self._seen = set()
+
+    def _launch(self, b):
+        flat, items = self.buckets[b]
+        for p, off, n in items:
+            if p.grad is None:
+                flat[off:off + n].zero_()
+            else:
+                flat[off:off + n].copy_(p.grad.reshape(-1))
+        if self.world > 1:
+            self._works[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        if p in self._seen:
+            return
+        self._seen.add(p)
+        b = self._where[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """wait for the collectives, write the averaged gradients back, re-arm for the next step"""
+        for b, (flat, items) in enumerate(self.buckets):
+            if self._pending[b] > 0:          # holds parameters without a gradient this step
+                self._launch(b)
+            if self._works[b] is not None:
+                self._works[b].wait()
+            if self.world > 1:
+                flat.div_(self.world)
+            for p, off, n in items:
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                elif self.world > 1:
+                    p.grad = flat[off:off + n].view_as(p).clone()
+        self._arm()
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
