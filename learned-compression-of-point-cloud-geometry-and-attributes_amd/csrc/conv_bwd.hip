@@ -25,6 +25,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int WG_SPLIT = 32;
+constexpr int WG_SPLIT_THIN = 256;     // the scalar kernel walks its rows serially: many short walks
 constexpr uint32_t WG_OOB = 0xFFFFF000u;
 [[maybe_unused]] constexpr uint32_t WG_FLAGS = 0x00020000u;
 
@@ -82,9 +83,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const bool live_m[2] = {2 * wm < cbi, 2 * wm + 1 < cbi};
     const bool live_n[2] = {2 * wn < cbo, 2 * wn + 1 < cbo};
 
-    for (int64_t g = s; g < ng; g += WG_SPLIT) {
-        const uint32_t gm = __builtin_amdgcn_readfirstlane(a.gmask ? a.gmask[g] : 0xffffffffu);
-        if (!((gm >> k) & 1u)) continue;                  // wave-uniform: no row of the group has this offset
+    // my groups are s, s + SPLIT, ...; 64 of their masks are inspected per load (one per lane) and only the
+    // groups that hold offset k are visited: a dependent scalar load per skipped group would cost ~1 us each
+    for (int64_t gbase = s; gbase < ng; gbase += 64 * WG_SPLIT) {
+      const int64_t gmine = gbase + (int64_t)lane * WG_SPLIT;
+      const uint32_t gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
+      unsigned long long live = __ballot((gml >> k) & 1u);
+      while (live) {
+        const int bit = __ffsll(live) - 1;
+        live &= live - 1;
+        const int64_t g = gbase + (int64_t)bit * WG_SPLIT;
         // wave w stages chunk w of both operands: 4 instructions x 8 rows each
         uint32_t voa[4], vob[4];
 #pragma unroll
@@ -116,6 +124,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
         }
         __syncthreads();
+      }
     }
 
     // D[row = (reg & 3) + 8 (reg >> 2) + 4 h][col = r] of each 32 x 32 tile: row = input channel, col = output channel
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // thin shapes (cin or cout not a multiple of 32: q-map branches, input layer, narrow heads): cin * cout <= 4096.
 // One workgroup per (offset, split); a thread owns (ci, co) pairs and walks the split's rows.
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a) {
-    const int k = blockIdx.x / WG_SPLIT, s = blockIdx.x % WG_SPLIT;
+    const int k = blockIdx.x / WG_SPLIT_THIN, s = blockIdx.x % WG_SPLIT_THIN;
     const int pairs = a.cin * a.cout;
     float acc[16];
     int ci[16], co[16];
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a)
         ci[q] = e / a.cout;
         co[q] = e - ci[q] * a.cout;
     }
-    const int64_t per = (a.n_out + WG_SPLIT - 1) / WG_SPLIT;
+    const int64_t per = (a.n_out + WG_SPLIT_THIN - 1) / WG_SPLIT_THIN;
     const int64_t lo = s * per, hi = min(a.n_out, lo + per);
     for (int64_t pos = lo; pos < hi; ++pos) {
         const int idx = a.nbr[pos * a.K + k];
@@ -202,10 +211,14 @@ int pcc_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64
     return PCC_OK;
 }
 
-static inline bool wgrad_rowsplit(int cin, int cout) { return cin % 32 == 0 && cout % 32 == 0 && cin <= 64 && cout <= 64; }
+static inline bool wgrad_mfma(int cin, int cout) { return cin % 32 == 0 && cout % 32 == 0; }
+static inline bool wgrad_rowsplit(int cin, int cout) { return wgrad_mfma(cin, cout) && cin <= 64 && cout <= 64; }
+static inline int wgrad_partials(int cin, int cout) {
+    return !wgrad_mfma(cin, cout) ? WG_SPLIT_THIN : WG_SPLIT * (wgrad_rowsplit(cin, cout) ? 4 : 1);
+}
 
 int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout) {
-    return (int64_t)WG_SPLIT * (wgrad_rowsplit(cin, cout) ? 4 : 1) * K * cin * cout;
+    return (int64_t)wgrad_partials(cin, cout) * K * cin * cout;
 }
 
 int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy, int64_t n_out, int32_t cout, const int32_t* nbr,
@@ -230,10 +243,10 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 8 * 1024 * sizeof(float), st, a);
     } else {
         PCC_REQUIRE((int64_t)cin * cout <= 4096, "pcc_conv_wgrad: thin path handles cin * cout <= 4096 (got %d x %d)", cin, cout);
-        hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3((unsigned)(K * WG_SPLIT)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3((unsigned)(K * WG_SPLIT_THIN)), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems,
-                       WG_SPLIT * (wgrad_rowsplit(cin, cout) ? 4 : 1), dw);
+                       wgrad_partials(cin, cout), dw);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
