@@ -24,7 +24,8 @@ namespace pcc {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int WG_SPLIT = 32;
+constexpr int WG_SPLIT_MAX = 128;     // row-group splits per (offset, weight block): the grid must be many times the chip
+                                      // (256 CUs x 5 workgroups) because offsets differ 3x in pair count (the centre has them all)
 constexpr int WG_SPLIT_THIN = 256;     // the scalar kernel walks its rows serially: many short walks
 constexpr uint32_t WG_OOB = 0xFFFFF000u;
 [[maybe_unused]] constexpr uint32_t WG_FLAGS = 0x00020000u;
@@ -46,9 +47,10 @@ struct WgradArgs {
     const int32_t* nbr;      // [n_out, K] in execution order
     const int32_t* order;    // [n_out] execution position -> row of dy, or null
     const uint32_t* gmask;   // [ceil(n_out / 32)] or null
-    float* partial;          // [WG_SPLIT, K, cin, cout]
+    float* partial;          // [splits, K, cin, cout]
     int64_t n_in, n_out;
     int cin, cout, K;
+    int split;               // row-group splits (MFMA kernel)
 };
 
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -59,7 +61,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);
-    const int k = blockIdx.x / WG_SPLIT, s = blockIdx.x % WG_SPLIT;
+    const int SPLIT = a.split;
+    const int k = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
     const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
     const int cbi = min(4, (a.cin - cin0) / 32), cbo = min(4, (a.cout - cout0) / 32);     // chunks present in this block
     // Blocks of at most 64 x 64 (64-channel layers) would leave three of the four waves without a tile:
@@ -85,14 +88,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     // my groups are s, s + SPLIT, ...; 64 of their masks are inspected per load (one per lane) and only the
     // groups that hold offset k are visited: a dependent scalar load per skipped group would cost ~1 us each
-    for (int64_t gbase = s; gbase < ng; gbase += 64 * WG_SPLIT) {
-      const int64_t gmine = gbase + (int64_t)lane * WG_SPLIT;
+    for (int64_t gbase = s; gbase < ng; gbase += 64 * SPLIT) {
+      const int64_t gmine = gbase + (int64_t)lane * SPLIT;
       const uint32_t gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
       unsigned long long live = __ballot((gml >> k) & 1u);
       while (live) {
         const int bit = __ffsll(live) - 1;
         live &= live - 1;
-        const int64_t g = gbase + (int64_t)bit * WG_SPLIT;
+        const int64_t g = gbase + (int64_t)bit * SPLIT;
         // wave w stages chunk w of both operands: 4 instructions x 8 rows each
         uint32_t voa[4], vob[4];
 #pragma unroll
@@ -213,12 +216,16 @@ int pcc_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64
 
 static inline bool wgrad_mfma(int cin, int cout) { return cin % 32 == 0 && cout % 32 == 0; }
 static inline bool wgrad_rowsplit(int cin, int cout) { return wgrad_mfma(cin, cout) && cin <= 64 && cout <= 64; }
-static inline int wgrad_partials(int cin, int cout) {
-    return !wgrad_mfma(cin, cout) ? WG_SPLIT_THIN : WG_SPLIT * (wgrad_rowsplit(cin, cout) ? 4 : 1);
+static inline int wgrad_splits(int64_t n_out) {            // at least ~48 row groups per workgroup
+    const int64_t want = ((n_out + 31) / 32) / 48;
+    return (int)(want < 8 ? 8 : (want > WG_SPLIT_MAX ? WG_SPLIT_MAX : want));
+}
+static inline int wgrad_partials(int cin, int cout, int split) {
+    return !wgrad_mfma(cin, cout) ? WG_SPLIT_THIN : split * (wgrad_rowsplit(cin, cout) ? 4 : 1);
 }
 
 int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout) {
-    return (int64_t)wgrad_partials(cin, cout) * K * cin * cout;
+    return (int64_t)wgrad_partials(cin, cout, WG_SPLIT_MAX) * K * cin * cout;
 }
 
 int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy, int64_t n_out, int32_t cout, const int32_t* nbr,
@@ -235,18 +242,18 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
     }
     WgradArgs a;
     a.fin = fin; a.dy = dy; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.partial = scratch;
-    a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.K = K;
+    a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.K = K; a.split = wgrad_splits(n_out);
     if (cin % 32 == 0 && cout % 32 == 0) {
         PCC_REQUIRE((uint64_t)n_in * cin * 4 <= WG_OOB && (uint64_t)n_out * cout * 4 <= WG_OOB,
                     "pcc_conv_wgrad: operands of 4 GiB and more are not supported yet");
-        const dim3 grid((unsigned)(K * WG_SPLIT), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
+        const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 8 * 1024 * sizeof(float), st, a);
     } else {
         PCC_REQUIRE((int64_t)cin * cout <= 4096, "pcc_conv_wgrad: thin path handles cin * cout <= 4096 (got %d x %d)", cin, cout);
         hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3((unsigned)(K * WG_SPLIT_THIN)), dim3(256), 0, st, a);
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems,
-                       wgrad_partials(cin, cout), dw);
+                       wgrad_partials(cin, cout, a.split), dw);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
