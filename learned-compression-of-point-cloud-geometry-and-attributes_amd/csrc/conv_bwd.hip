@@ -150,24 +150,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // thin shapes (cin or cout not a multiple of 32: q-map branches, input layer, narrow heads): cin * cout <= 4096.
-// One workgroup per (offset, split); a thread owns (ci, co) pairs and walks the split's rows.
+// One workgroup per (offset, split).  With >= 256 (ci, co) pairs a thread owns up to 16 pairs and walks the
+// split's rows; with fewer pairs (64 -> 1: the occupancy head on 5 M candidates) the spare threads take
+// every RL-th row instead and the row lanes are summed through LDS at the end.
 __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a) {
+    __shared__ float red[256];
     const int k = blockIdx.x / WG_SPLIT_THIN, s = blockIdx.x % WG_SPLIT_THIN;
     const int pairs = a.cin * a.cout;
+    int pp = 1;
+    while (pp < pairs && pp < 256) pp <<= 1;              // pairs rounded up to a power of two, at most 256
+    const int RL = 256 / pp;                                // row lanes (1 when pairs >= 256)
+    const int pid = threadIdx.x % pp, rl = threadIdx.x / pp;
     float acc[16];
     int ci[16], co[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         acc[q] = 0.0f;
-        const int e = min(threadIdx.x + 256 * q, pairs - 1);
+        const int e = min(pid + 256 * q, pairs - 1);
         ci[q] = e / a.cout;
         co[q] = e - ci[q] * a.cout;
     }
     const int64_t per = (a.n_out + WG_SPLIT_THIN - 1) / WG_SPLIT_THIN;
     const int64_t lo = s * per, hi = min(a.n_out, lo + per);
-    for (int64_t pos = lo; pos < hi; ++pos) {
+    for (int64_t pos = lo + rl; pos < hi; pos += RL) {
         const int idx = a.nbr[pos * a.K + k];
-        if (idx < 0) continue;                                          // block-uniform
+        if (idx < 0) continue;
         const int64_t row = a.order ? a.order[pos] : pos;
         const float* x = a.fin + (int64_t)idx * a.cin;
         const float* y = a.dy + row * a.cout;
@@ -177,6 +184,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WgradArgs a)
         }
     }
     float* P = a.partial + ((int64_t)s * a.K + k) * pairs;
+    if (RL > 1) {                                           // pairs < 256: only acc[0] is in use
+        red[threadIdx.x] = acc[0];
+        __syncthreads();
+        if (rl == 0 && pid < pairs) {
+            float sum = 0.0f;
+            for (int l = 0; l < RL; ++l) sum += red[l * pp + pid];        // fixed order
+            P[pid] = sum;
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int e = threadIdx.x + 256 * q;
