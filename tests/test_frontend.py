@@ -115,3 +115,14 @@ def test_harness_file_mode_row(pcc, tmp_path):
     qa = np.full((pts.shape[0], 1), 0.5, dtype=np.float32)
     row2 = evaluate_frame("exp2", model, data, qa, qa, "cuda:0", str(tmp_path), resolution=31)
     assert row2["bpp"] == row["bpp"]
+
+
+def test_sparse_collate(pcc):
+    from pcc_amd.utils import sparse_collate
+    a, b = cloud(50, 1), cloud(70, 2)
+    C, F = sparse_collate([torch.from_numpy(a[:, :3]), torch.from_numpy(b[:, :3])], [torch.from_numpy(a[:, 3:]), torch.from_numpy(b[:, 3:])])
+    assert C.dtype == torch.int32 and C.shape == (a.shape[0] + b.shape[0], 4) and F.shape == (C.shape[0], 3)
+    assert (C[:a.shape[0], 0] == 0).all() and (C[a.shape[0]:, 0] == 1).all()
+    assert torch.equal(C[a.shape[0]:, 1:].float(), torch.from_numpy(b[:, :3]))
+    with pytest.raises(ValueError):
+        sparse_collate([torch.zeros(3, 3)], [torch.zeros(2, 3)])
