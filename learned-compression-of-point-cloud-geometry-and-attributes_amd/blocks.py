@@ -5,6 +5,8 @@ that reference checkpoints load with ``strict=True``; the forward passes are re-
 the fused HIP convolution (bias + FiLM + activation + residual in the epilogue, shared kernel
 maps, outputs evaluated only where the reference reads them).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -68,6 +70,46 @@ class ScaledBlock(nn.Module):
         return self.conv_2(h, last_residual=x.F)
 
 
+_SIDE_STREAMS = {}
+
+
+def prefetch_up_maps(x_map):
+    """Build, on a side stream, the coordinate set and kernel maps the next GenerativeUpBlock will need for
+    ``x_map`` (candidates = k3 children; parent->candidate map; candidate->candidate maps).  They are pure
+    functions of the coordinates, cached on the CoordMaps, and made of hash probes and sorts — memory-
+    latency work that runs beside the MFMA-bound convolutions of the same stage (q_predict, ScaledBlock)
+    instead of in front of the up block.  Inference path only.
+
+    Allocator note: everything allocated here belongs to the side stream's pool; a freed block can only be
+    handed out again by a later prefetch, which starts with ``side.wait_stream(main)`` — after every main-
+    stream kernel that read the block was enqueued."""
+    if os.environ.get("PCC_PREFETCH_MAPS", "1") == "0" or torch.is_grad_enabled():
+        return
+    key = ("okmap_prefetched",)
+    if x_map._cache.get(key):
+        return
+    dev = x_map.device
+    side = _SIDE_STREAMS.get(dev)
+    if side is None:
+        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        cand = x_map.up(3)
+        x_map.ordered_kernel_map(cand, 3, True)
+        cand.ordered_kernel_map(cand, 3)
+        cand.kernel_map(cand, 3)
+        x_map._cache[("prefetch_event",)] = side.record_event()
+    x_map._cache[key] = True
+
+
+def _join_prefetch(x_map):
+    ev = x_map._cache.pop(("prefetch_event",), None)
+    if ev is not None:
+        torch.cuda.current_stream(x_map.device).wait_event(ev)
+
+
 class GenerativeUpBlock(nn.Module):
     """model/blocks.py:78-181."""
 
@@ -88,6 +130,7 @@ class GenerativeUpBlock(nn.Module):
             return self._follow(x, coords)
         if not self.dense or self.condition_ablation is not None:
             raise NotImplementedError("dense=False / condition_ablation variants are outside BASELINE scope")
+        _join_prefetch(x.map)
         x = self.conv(x)                                   # genConvT k3 s2 -> all candidates
         x = self.conv_2(x)
         # only channel 0 of the occupancy head is ever read (blocks.py:142): evaluate just that

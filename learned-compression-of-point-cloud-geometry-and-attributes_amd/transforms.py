@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import sparse as sp
-from .blocks import ConditionEncoder, GenerativeUpBlock, ScaledBlock, _conv
+from .blocks import prefetch_up_maps, ConditionEncoder, GenerativeUpBlock, ScaledBlock, _conv
 from .sparse import ConvChain, CoordMap, MinkowskiConvolution, MinkowskiReLU, SparseTensor
 
 
@@ -144,6 +144,7 @@ class SparseSynthesisTransform(nn.Module):
         for i in range(3):
             # beta/gamma are only ever read at x's coordinates (blocks.py:37): evaluate the last conv of
             # q_predict there (identical values; it is the whole map when Q already lives on x's map)
+            prefetch_up_maps(x.map)          # side stream: the up block's coordinate set and kernel maps
             beta_gamma = q_predicts[i](Q, last_out_map=x.map)
             x = scales[i](x, beta_gamma)
             x, pred, up_map = ups[i](x, k=k[i], full_predictions=full_pred)
