@@ -81,12 +81,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    # PCC_BENCH_REHEARSE=1: rehearse the N > 1 control flow on a one-GPU box — every rank on cuda:0,
+    # collectives over gloo on host tensors (never a measurement)
+    rehearse = os.environ.get("PCC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = torch.device("cpu") if rehearse else dev          # device of the collectives' tensors
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import pcc_amd
     from pcc_amd import sparse as sp
@@ -109,7 +118,7 @@ def main():
     def gather_bitstreams(strings, shape, k):
         # frames are the sharded unit: every rank contributes its frame's container, all ranks end
         # up with the whole step's bitstreams (RCCL all-gather(v) over xGMI)
-        return par.all_gather_bitstreams(par.pack_unit(strings, shape, k), dev)
+        return par.all_gather_bitstreams(par.pack_unit(strings, shape, k), cdev)
 
     t_enc = t_dec = 0.0
     last = {}
@@ -149,10 +158,10 @@ def main():
     prof, sp.PROFILER = sp.PROFILER, None
 
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        ntot = torch.tensor([N], dtype=torch.int64, device=dev)
+        ntot = torch.tensor([N], dtype=torch.int64, device=cdev)
         dist.all_reduce(ntot)
         n_total = int(ntot.item())
     else:
