@@ -38,7 +38,7 @@ struct ConvArgs {
     const float* residual;  // [n_out, cout] or null
     int64_t n_in, n_out;
     int cin, cout, coutp, K, act;
-    int debug;   // development ablations, compiled in only with -DPCC_CONV_ABLATE (PCC_CONV_DEBUG): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no MFMA
+    int debug;   // development ablations of conv_mfma_kernel, compiled in only with -DPCC_CONV_ABLATE (PCC_CONV_DEBUG): 1 no DMA, 4 no barrier, 8 no MFMA, 16 no A DMA, 32 no W DMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -74,11 +74,10 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 #else
 #define DBG(a) 0
 #endif
-constexpr int A_LD_REG = 36;   // register-staged image: 32 + 4 pad floats per row -> conflict-free ds_read_b128
 constexpr int A_LD_DMA = 32;   // LDS-DMA image: unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
 
-template <int BM, int BN, bool DMA>
-constexpr int conv_lds_bytes() { return 2 * (BM * (DMA ? A_LD_DMA : A_LD_REG) + 8 * BN * 4) * (int)sizeof(float); }
+template <int BM, int BN>
+constexpr int conv_lds_bytes() { return 2 * (BM * A_LD_DMA + 8 * BN * 4) * (int)sizeof(float); }
 
 // 1 KB of zeros: the gather source of absent neighbours on the LDS-DMA path
 __device__ float g_zero_line[256] = {0.0f};   // cin <= 256: the per-step channel offset stays inside
@@ -86,18 +85,16 @@ __device__ float g_zero_line[256] = {0.0f};   // cin <= 256: the per-step channe
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
-// Staging variants of the same kernel:
-//   DMA = false  global_load_dwordx4 -> VGPR -> (zero select) -> ds_write_b128, padded A image
-//   DMA = true   global_load_lds_dwordx4 straight into LDS (no staging registers, no ds_write): the
-//                A image is unpadded; each 16-B slot p of row R holds global chunk p ^ ((R >> 1) & 7),
-//                the permutation being applied on the per-lane SOURCE address (the LDS side of an
-//                LDS-DMA is lane-linear) and undone on the fragment reads.
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR, bool DMA>
+// 64-bit-addressed variant (operands of 4 GiB and more; PCC_CONV_PATH=global): both operands go global ->
+// LDS with global_load_lds_dwordx4 (no staging registers, no ds_write).  The A image is unpadded; each
+// 16-B slot p of row R holds global chunk p ^ ((R >> 1) & 7), the permutation being applied on the
+// per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear) and undone on the fragment reads.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     constexpr int RPT = BM / 32;              // gather rows per thread (8 lanes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
-    constexpr int A_LD = DMA ? A_LD_DMA : A_LD_REG;
+    constexpr int A_LD = A_LD_DMA;
     constexpr int A_ELEMS = BM * A_LD;
     constexpr int W_ELEMS = 8 * BN * 4;
     constexpr int W_LOADS = (8 * BN) / 256;  // float4 per thread per chunk
@@ -156,11 +153,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     const int gchunk = t & 7;
     int grow[RPT];
 #pragma unroll
-    for (int i = 0; i < RPT; ++i) grow[i] = DMA ? (wid * (BM / 4) + 8 * i + (lane >> 3)) : ((t >> 3) + 32 * i);
+    for (int i = 0; i < RPT; ++i) grow[i] = wid * (BM / 4) + 8 * i + (lane >> 3);
     int idx_cur[RPT], idx_nxt[RPT];
-    f32x4 areg[RPT];
-    bool amask[RPT];
-    f32x4 wreg[W_LOADS];
     // per-thread constants of the tile: which of my 4 gather rows exist, and where their nbr rows start.
     // Index loads are kept raw (no select on the loaded value) so that hipcc does not wait for them
     // at the point of issue; validity is folded in when the index is consumed.
@@ -180,35 +174,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
 #pragma unroll
             for (int i = 0; i < RPT; ++i) dst[i] = nbr_row[i][k];
         }
-    };
-    // ---- register-staged path --------------------------------------------------------------------
-    auto load_step = [&](int k, int c, const int (&idx)[RPT]) {
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            // absent neighbours read row 0 (always valid, L1-resident) and are zeroed in store_step
-            const bool ok = rvalid[i] && idx[i] >= 0;
-            const int64_t src = ok ? idx[i] : 0;
-            areg[i] = *reinterpret_cast<const f32x4*>(a.fin + src * a.cin + c * 32 + gchunk * 4);
-            amask[i] = ok;
-        }
-        const float* wbase = a.wp + (((int64_t)k * (a.cin / 4) + c * 8) * a.coutp + nt * BN) * 4;
-#pragma unroll
-        for (int j = 0; j < W_LOADS; ++j) {
-            const int f = t + 256 * j;
-            const int g = f / BN, col = f - g * BN;
-            wreg[j] = *reinterpret_cast<const f32x4*>(wbase + ((int64_t)g * a.coutp + col) * 4);
-        }
-    };
-    auto store_step = [&](int buf) {
-        float* Ab = As + buf * A_ELEMS;
-        float* Wb = Ws + buf * W_ELEMS;
-#pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-            *reinterpret_cast<f32x4*>(Ab + grow[i] * A_LD + gchunk * 4) = amask[i] ? areg[i] : z;
-        }
-#pragma unroll
-        for (int j = 0; j < W_LOADS; ++j) *reinterpret_cast<f32x4*>(Wb + (t + 256 * j) * 4) = wreg[j];
     };
     // ---- LDS-DMA path ----------------------------------------------------------------------------
     // Per-lane source row pointers (already at my swizzled 16-B chunk) are recomputed only when the
@@ -256,7 +221,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     int a_off[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
-        a_off[kk] = DMA ? ((((kk ^ (sw >> 1)) << 1) | (h ^ (sw & 1))) * 4) : (8 * kk + 4 * h);
+        a_off[kk] = (((kk ^ (sw >> 1)) << 1) | (h ^ (sw & 1))) * 4;
 
     // MFMA block of one step, specialised at compile time on WHICH of the wave's 32-row tiles have
     // offset k (LIVE bit m = tile m).  Every variant is straight-line code: fragments of sub-block
@@ -321,8 +286,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         rem &= rem - 1u;
         int knext = rem ? __builtin_ctz(rem) : -1;
         load_idx(k, idx_cur);
-        if constexpr (DMA) { set_a_src(idx_cur); dma_step(k, 0, 0); }
-        else { load_step(k, 0, idx_cur); store_step(0); }
+        set_a_src(idx_cur);
+        dma_step(k, 0, 0);
         load_idx(knext >= 0 ? knext : k, idx_nxt);
         __syncthreads();        // (emits vmcnt(0): the first DMA / loads have landed)
         int c = 0, cur = 0;
@@ -334,12 +299,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             if (advance) {
 #pragma unroll
                 for (int i = 0; i < RPT; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
-                if constexpr (DMA) set_a_src(idx_cur);
+                set_a_src(idx_cur);
             }
             if (has_next && !(DBG(a) & 1)) {
                 // buffer cur^1 was last read in the previous step, which every wave has left (barrier)
-                if constexpr (DMA) dma_step(nk, nc, cur ^ 1);
-                else load_step(nk, nc, idx_cur);
+                dma_step(nk, nc, cur ^ 1);
             }
             // indices of the offset after next: issued a full step (or more) before their first use
             uint32_t rem2 = rem;
@@ -347,7 +311,6 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             if (advance) { rem2 &= rem2 - 1u; kn2 = rem2 ? __builtin_ctz(rem2) : -1; }
             load_idx(kn2 >= 0 ? kn2 : k, idx_nxt);
             if (!(DBG(a) & 8)) compute(cur, k);
-            if constexpr (!DMA) { if (has_next && !(DBG(a) & 2)) store_step(cur ^ 1); }
             if (!(DBG(a) & 4)) __syncthreads();     // vmcnt(0) + lgkmcnt(0) + barrier: next image complete
             if (!has_next) break;
             if (advance) { k = nk; rem = rem2; knext = kn2; }
@@ -733,13 +696,13 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR, bool DMA>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
 static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, HAS_NBR, DMA>;
+    auto kern = conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, HAS_NBR>;
     static int extra_lds = -1;      // development knob: PCC_CONV_EXTRA_LDS=<bytes> lowers workgroups per CU
     if (extra_lds < 0) { const char* e = getenv("PCC_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
-    const int lds = conv_lds_bytes<BM, BN, DMA>() + extra_lds;
+    const int lds = conv_lds_bytes<BM, BN>() + extra_lds;
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -756,7 +719,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR>
 static int launch_mfma_buf_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
     auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR>;
-    const int lds = conv_lds_bytes<BM, BN, true>();
+    const int lds = conv_lds_bytes<BM, BN>();
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -791,7 +754,7 @@ static int launch_mfma(const ConvArgs& a, hipStream_t st) {
         }
 #undef PCC_BUF_CASE
     }
-    return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true, true>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false, true>(a, st);
+    return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false>(a, st);
 }
 
 template <int CIN>
