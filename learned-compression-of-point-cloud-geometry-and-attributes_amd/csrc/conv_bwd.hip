@@ -65,11 +65,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int k = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
     const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
     const int cbi = min(4, (a.cin - cin0) / 32), cbo = min(4, (a.cout - cout0) / 32);     // chunks present in this block
-    // Blocks of at most 64 x 64 (64-channel layers) would leave three of the four waves without a tile:
-    // there the waves split the group's 32 ROWS instead (8 each) and write one partial per wave.
+    // Blocks of at most 64 x 64 (64-channel layers) would leave three of the four waves without a tile and
+    // half of the LDS images empty: there an iteration takes TWO row groups (waves 0-1 stage and consume the
+    // first in image slots 0-1, waves 2-3 the second in slots 2-3), each wave multiplies 16 of its group's 32
+    // rows into the whole 64 x 64 block, and every wave writes its own partial.
     const bool rowsplit = a.cin <= 64 && a.cout <= 64;       // a property of the layer, not of the block (host agrees)
     const int wm = rowsplit ? 0 : wave_u >> 1, wn = rowsplit ? 0 : wave_u & 1;           // 64 x 64 sub-block of the wave
-    const int kp0 = rowsplit ? 4 * wave_u : 0, kp1 = rowsplit ? 4 * wave_u + 4 : 16;
+    const int kp0 = rowsplit ? 8 * (wave_u & 1) : 0, kp1 = rowsplit ? kp0 + 8 : 16;
+    const int cw = rowsplit ? (wave_u & 1) : wave_u;                                      // chunk this wave stages
+    const int slotA = rowsplit ? 2 * (wave_u >> 1) : 2 * wm, slotB = rowsplit ? 2 * (wave_u >> 1) : 2 * wn;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -95,17 +99,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
       while (live) {
         const int bit = __ffsll(live) - 1;
         live &= live - 1;
-        const int64_t g = gbase + (int64_t)bit * SPLIT;
-        // wave w stages chunk w of both operands: 4 instructions x 8 rows each
+        int64_t g = gbase + (int64_t)bit * SPLIT;
+        if (rowsplit) {                                   // second group of the iteration (or none: zero images)
+            int64_t g2 = -1;
+            if (live) {
+                g2 = gbase + (int64_t)(__ffsll(live) - 1) * SPLIT;
+                live &= live - 1;
+            }
+            if (wave_u >= 2) g = g2;
+        }
+        // wave w stages one chunk of both operands: 4 instructions x 8 rows each
         uint32_t voa[4], vob[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t pos = g * 32 + 8 * i + rsub;
-            const bool ok = pos < a.n_out;
+            const bool ok = g >= 0 && pos < a.n_out;
             const int idx = ok ? a.nbr[pos * a.K + k] : -1;
             const int64_t row = ok ? (a.order ? a.order[pos] : pos) : 0;
-            voa[i] = (idx >= 0 && wave_u < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 4) + (uint32_t)((cin0 + wave_u * 32) * 4 + slot * 16) : WG_OOB;
-            vob[i] = (ok && wave_u < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 4) + (uint32_t)((cout0 + wave_u * 32) * 4 + slot * 16) : WG_OOB;
+            voa[i] = (idx >= 0 && cw < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 4) + (uint32_t)((cin0 + cw * 32) * 4 + slot * 16) : WG_OOB;
+            vob[i] = (ok && cw < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 4) + (uint32_t)((cout0 + cw * 32) * 4 + slot * 16) : WG_OOB;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -113,8 +125,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Bs + wave_u * 1024 + i * 256), 16, vob[i], 0, 0, 0);
         }
         __syncthreads();
-        const float* Ab = As + (2 * wm) * 1024 + h * 32 + r;
-        const float* Bb = Bs + (2 * wn) * 1024 + h * 32 + r;
+        const float* Ab = As + slotA * 1024 + h * 32 + r;
+        const float* Bb = Bs + slotB * 1024 + h * 32 + r;
         for (int kp = kp0; kp < kp1; ++kp) {
             float av[2], bv[2];
 #pragma unroll
