@@ -26,6 +26,13 @@ def coord_noise(shape, coords):
     return torch.from_numpy(val.reshape(shape))
 
 
+def coord_noise_b(shape, coords):
+    """like coord_noise, with the batch index in the key (two items may share x, y, z)"""
+    c = np.asarray(coords, dtype=np.float64).copy()
+    c[:, 1] += 1000.0 * c[:, 0]
+    return coord_noise(shape, c)
+
+
 def _setup(pcc):
     from pcc_amd import synthetic as syn
     model = syn.make_model(seed=0, device=DEV)
@@ -125,3 +132,55 @@ def test_optimizer_step_reduces_the_loss(pcc):
     aux = model.aux_loss()
     aux.backward()
     assert model.entropy_model.entropy_bottleneck.quantiles.grad is not None
+
+
+def test_training_step_batch_of_two_matches_oracle(pcc):
+    """two clouds in one batch (train.py:185-194: sparse_collate): per-item top-k, per-item q-maps"""
+    from pcc_amd import entropy as pe, synthetic as syn
+    from pcc_amd.loss import OURS_LOSS, Loss
+    from pcc_amd.utils import sparse_collate
+    model = syn.make_model(seed=0, device=DEV)
+    model.train()
+    a = syn.sphere_shell(**syn.CONFIG1)
+    b = syn.sphere_shell(grid=32, radius=11.0, half_width=0.8)
+    C, F = sparse_collate([torch.from_numpy(a[:, :3]), torch.from_numpy(b[:, :3])], [torch.from_numpy(a[:, 3:]), torch.from_numpy(b[:, 3:])])
+    qc = C.numpy().astype(np.float32)
+    colors = F.numpy()
+    qf = np.concatenate([np.tile([[0.3, 0.7]], (a.shape[0], 1)), np.tile([[0.8, 0.2]], (b.shape[0], 1))]).astype(np.float32)
+    lam = np.stack([2 ** (qf[:, 0] * 6) + 24, 2 ** (qf[:, 1] * 7) + 99], axis=1).astype(np.float32)
+    inp = pcc.SparseTensor(coordinates=C.to(DEV), features=F.to(DEV), device=DEV)
+    Q = pcc.SparseTensor(torch.from_numpy(qf).to(DEV), coordinate_map=inp.map)
+    Lam = pcc.SparseTensor(torch.from_numpy(lam).to(DEV), coordinate_map=inp.map)
+    pe.NOISE_SOURCE = coord_noise_b
+    try:
+        out = model(inp, Q, Lam)
+    finally:
+        pe.NOISE_SOURCE = None
+    total, parts = Loss(OURS_LOSS)(inp, out)
+    total.backward()
+    sd = ot.leaf_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    codec = Codec(sd)
+    codec.sd, codec.p = sd, type(codec.p)(sd)
+    codec.eb = type(codec.eb)(codec.p.sub("entropy_model").sub("entropy_bottleneck"))
+    o_out = ot.forward_train(codec, qc, colors, qc, qf, coord_noise_b)
+    o_total, o_parts = ot.losses(qc, colors, o_out, OSparseTensor(qc, torch.from_numpy(lam), 1))
+    o_total.backward()
+    assert o_out["k"] == [[int(v) for v in kk] for kk in o_out["k"]] and len(o_out["k"][0]) == 2      # per-item counts
+    got_c = set(map(tuple, out["prediction"].C.cpu().numpy().tolist()))
+    assert got_c == set(map(tuple, o_out["prediction"].C.tolist()))                    # no top-k boundary flips
+    named = dict(model.named_parameters())
+    worst = (0.0, None)
+    errs = []
+    for name, leaf in sd.items():
+        if leaf.grad is None or name not in named or float(leaf.grad.abs().max()) == 0.0:
+            continue
+        err = float((named[name].grad.cpu() - leaf.grad).abs().max()) / float(leaf.grad.abs().max())
+        worst = max(worst, (err, name))
+        errs.append((err, name))
+    # A pre-activation within ~1e-6 of zero can land on either side of a ReLU in two fp32 implementations; one
+    # such element (seen here: one channel of one voxel in post_conv.0, |pre-activation| 2.3e-6) moves the
+    # max-norm error of that layer's weight gradient to 2 % while every other gradient agrees to < 1e-3.
+    # So: a tight bound on all but a few tensors, a loose one on every tensor.
+    errs.sort(reverse=True)
+    assert errs[0][0] < 5e-2, errs[:3]
+    assert sum(1 for e, _ in errs if e > 5e-3) <= 3, errs[:6]

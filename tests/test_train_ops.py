@@ -111,3 +111,27 @@ def test_fused_epilogue_terms_and_channel_slice_are_differentiated(pcc):
     g = layer.kernel.grad
     assert float(g[:, :, 1:].abs().max()) == 0.0 and float(g[:, :, 0].abs().max()) > 0
     assert float(layer.bias.grad[0, 1:].abs().max()) == 0.0
+
+
+def test_conv_gradients_with_two_batch_items(pcc):
+    """two items that overlap in (x, y, z): neighbours never cross items, forward or backward"""
+    torch.manual_seed(9)
+    a = shell()
+    b = shell(radius=10.0)
+    b[:, 0] = 1
+    c = np.concatenate([a, b], axis=0)
+    n = c.shape[0]
+    for cin, cout in [(64, 64), (128, 128), (4, 64)]:
+        layer = pcc.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
+        F, G = torch.randn(n, cin), torch.randn(n, cout)
+        x = F.to(DEV).requires_grad_(True)
+        out = layer(pcc.SparseTensor(x, coordinate_map=pcc.CoordMap(torch.from_numpy(c).to(DEV), 1))).F
+        (out * G.to(DEV)).sum().backward()
+        Fo = F.clone().requires_grad_(True)
+        Wo = layer.kernel.detach().cpu().clone().requires_grad_(True)
+        bo = layer.bias.detach().cpu().clone().requires_grad_(True)
+        ref = on._apply_conv(Fo, Wo, bo, oc.kernel_map(c, c, 3, 1), n)
+        (ref * G).sum().backward()
+        assert close(out.detach().cpu(), ref.detach())
+        assert close(x.grad.cpu(), Fo.grad), ("dX", cin, cout)
+        assert close(layer.kernel.grad.cpu(), Wo.grad), ("dW", cin, cout)
