@@ -155,6 +155,10 @@ int pcc_gather_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, 
 /* out[idx[i],:] = src[i,:] for idx[i] >= 0 (re-indexing a tensor onto another map). */
 int pcc_scatter_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out,
                      void* stream);
+/* out[idx[i],:] += src[i,:] for idx[i] >= 0: the backward of pcc_gather_rows (training path; the
+ * reference gets it from torch's indexing autograd behind features_at_coordinates, loss.py:103-107). */
+int pcc_scatter_add_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out,
+                         void* stream);
 
 /* ME.MinkowskiPruning (model/blocks.py:90,126): order-preserving compaction of the rows
  * with mask != 0.  Either of feats/out_feats and coords/out_coords may be NULL.

@@ -38,6 +38,7 @@ SIGNATURES = {
     "pcc_gather_sum_fwd": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "pcc_gather_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_void_p]),
     "pcc_scatter_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pcc_scatter_add_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),
     "pcc_compact_rows": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_topk_state_elems": (c_i64, [c_i32]),
     "pcc_topk_mask": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -354,6 +354,20 @@ __global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restri
     }
 }
 
+// out[idx[r], :] += src[r, :]: the backward of a row gather (training path).  Float atomics: the sum order is
+// unspecified only where several source rows hit the same target (repeated queries).
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float* __restrict__ src, int c,
+                                                               const int32_t* __restrict__ idx, int64_t n,
+                                                               float* __restrict__ out) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / c;
+        const int col = (int)(e - r * c);
+        const int32_t d = idx[r];
+        if (d >= 0) atomicAdd(&out[(int64_t)d * c + col], src[e]);
+    }
+}
+
 __global__ __launch_bounds__(256) void mask_to_flags(const uint8_t* __restrict__ mask, int64_t n,
                                                      int32_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -505,6 +519,14 @@ int pcc_gather_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, 
 int pcc_scatter_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out, void* stream) {
     if (n <= 0 || c <= 0) return PCC_OK;
     hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks_for(n * c, 256, 65536)), dim3(256), 0, as_stream(stream), src,
+                       c, idx, n, out);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_scatter_add_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out, void* stream) {
+    if (n <= 0 || c <= 0) return PCC_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(blocks_for(n * c, 256, 65536)), dim3(256), 0, as_stream(stream), src,
                        c, idx, n, out);
     PCC_LAUNCH_CHECK();
     return PCC_OK;

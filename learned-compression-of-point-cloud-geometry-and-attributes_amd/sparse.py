@@ -233,11 +233,34 @@ def _tracked(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+class _GatherRowsFn(torch.autograd.Function):
+    """rows = src[idx] (zeros where idx < 0) on the HIP row movers, both directions (torch's index_select
+    backward takes 14 ms for 812 k x 3 on this stack; the atomic scatter-add 0.1 ms)"""
+
+    @staticmethod
+    def forward(ctx, src, idx):
+        src = src.contiguous()
+        n, c = idx.shape[0], src.shape[1]
+        out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+        check(_lib.lib().pcc_gather_rows(ptr(src), c, ptr(idx), n, ptr(out), 0, _lib.stream()))
+        ctx.save_for_backward(idx)
+        ctx.rows = src.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        d = torch.zeros((ctx.rows, g.shape[1]), dtype=torch.float32, device=g.device)
+        check(_lib.lib().pcc_scatter_add_rows(ptr(g), g.shape[1], ptr(idx), idx.shape[0], ptr(d), _lib.stream()))
+        return d, None
+
+
 def gather_rows(src, idx, out=None, accumulate=False):
     """out[r] (+)= src[idx[r]] (zero rows where idx < 0).  Returns the result: callers must use the return
     value (on the training path a new tensor is returned instead of writing into ``out``)."""
     if _tracked(src, out):
-        sel = src.index_select(0, idx.clamp(min=0).long()) * (idx >= 0).unsqueeze(1).to(src.dtype)
+        sel = _GatherRowsFn.apply(src, idx.contiguous())
         return out + sel if (accumulate and out is not None) else sel
     n = idx.shape[0]
     c = src.shape[1]
