@@ -9,7 +9,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 constexpr int CIN = 128, COUT = 128, K = 27;
-template <int NBUF>
+template <int NBUF, bool RANDOM>
 __global__ __launch_bounds__(256) void k(const float* __restrict__ fin, const float* __restrict__ wp, const int* __restrict__ nbr,
                                           float* __restrict__ fout, int n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -30,7 +30,9 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ fin, const fl
     const float* a_src[2];
     auto set_src = [&](int kk) {
         for (int i = 0; i < 2; ++i) {
-            int64_t src = row0 + grow[i] + 3 * kk; if (src >= n) src -= n;
+            int64_t src;
+            if (RANDOM) { uint64_t hsh = (uint64_t)(row0 + grow[i]) * 0x9E3779B97F4A7C15ull + (uint64_t)kk * 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 29; src = (int64_t)(hsh % (uint64_t)n); }
+            else { src = row0 + grow[i] + 3 * kk; if (src >= n) src -= n; }
             const int q = gchunk ^ ((grow[i] >> 1) & 7);
             a_src[i] = fin + src * CIN + q * 4;
         }
@@ -91,21 +93,21 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ fin, const fl
             if (pos < n) fout[pos * COUT + wcol + 32 * nn + r] = acc[nn][reg];
         }
 }
-template <int NBUF>
+template <int NBUF, bool RANDOM>
 void run(int n, int extra) {
     float *fin, *wp, *fout;
     (void)hipMalloc(&fin, (size_t)n * CIN * 4); (void)hipMalloc(&wp, (size_t)K * CIN * COUT * 4); (void)hipMalloc(&fout, (size_t)n * COUT * 4);
     (void)hipMemset(fin, 0, (size_t)n * CIN * 4); (void)hipMemset(wp, 0, (size_t)K * CIN * COUT * 4);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     const int lds = NBUF * (2048 + 4096) * 4 + extra;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k<NBUF>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k<NBUF, RANDOM>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     for (int rep = 0; rep < 3; ++rep) {
         (void)hipEventRecord(e0);
-        hipLaunchKernelGGL(k<NBUF>, dim3(n / 64), dim3(256), lds, 0, fin, wp, nullptr, fout, n);
+        hipLaunchKernelGGL((k<NBUF, RANDOM>), dim3(n / 64), dim3(256), lds, 0, fin, wp, nullptr, fout, n);
         (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
         float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (rep == 2) printf("NBUF=%d lds=%d n=%d  %.3f ms  %.1f TFLOP/s\n", NBUF, lds, n, ms, 2.0 * n * K * CIN * COUT / ms / 1e9);
+        if (rep == 2) printf("%s NBUF=%d lds=%d n=%d  %.3f ms  %.1f TFLOP/s\n", RANDOM ? "random" : "local ", NBUF, lds, n, ms, 2.0 * n * K * CIN * COUT / ms / 1e9);
     }
     (void)hipFree(fin); (void)hipFree(wp); (void)hipFree(fout);
 }
-int main() { run<2>(1 << 20, 0); run<2>(1 << 20, 24576); run<3>(1 << 20, 0); run<4>(1 << 20, 0); return 0; }
+int main() { const int n = 5 << 20; run<2, false>(n, 0); run<2, true>(n, 0); run<2, true>(n, 24576); run<3, true>(n, 0); run<4, true>(n, 0); return 0; }
