@@ -216,7 +216,10 @@ def main():
                     "launches_per_step": d["launches"] / args.steps,
                     "avg_launch_ms": d["ms"] / d["launches"],
                     "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                    "share_of_step_time": d["ms"] * 1e-3 / elapsed}
+                    "share_of_step_time": d["ms"] * 1e-3 / elapsed,
+                    # the same launches seen from the memory side: measured HBM bytes (PMC) over the measured duration
+                    "hbm_gbps": None if traffic is None else traffic / (d["ms"] / d["launches"] * 1e-3) / 1e9,
+                    "hbm_peak_gbps": 8000.0}
     if args.breakdown and rank == 0:
         tot_ms = sum(c["ms"] for c in classes.values())
         for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
