@@ -39,6 +39,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", default="256,100,0.5", help="grid,radius,half_width of the CPU-baseline shell")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
+    ap.add_argument("--partition", default="frames", choices=["frames", "blocks"],
+                    help="N > 1 sharding: one frame per rank (weak scaling, the default) or the cubes of ONE frame "
+                         "spread over the ranks (strong scaling; different numbers than whole-frame coding, SURVEY.md 8e)")
+    ap.add_argument("--block", type=int, default=512, help="cube edge of --partition blocks")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -105,7 +109,9 @@ def main():
 
     cfg = {"config1": syn.CONFIG1, "config2": syn.CONFIG2, "mid": dict(grid=256, radius=100.0, half_width=0.5)}[args.workload]
     cfg = dict(cfg)
-    cfg["radius"] = cfg["radius"] - 0.25 * rank            # rank r codes its own frame
+    blocks_mode = args.partition == "blocks"
+    if not blocks_mode:
+        cfg["radius"] = cfg["radius"] - 0.25 * rank        # rank r codes its own frame
     pts = syn.sphere_shell(**cfg)
     N = pts.shape[0]
     qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
@@ -123,8 +129,30 @@ def main():
     t_enc = t_dec = 0.0
     last = {}
 
+    def step_blocks(timed):
+        """strong scaling: this rank codes and decodes its share of the frame's cubes, then all ranks exchange
+        the cubes' containers"""
+        nonlocal t_enc, t_dec
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, units = par.compress_blocks(model, x, q_feats, args.block, rank, world)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        rec = par.decompress_blocks(model, units) if units else None
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        if world > 1:
+            payload = b"".join(par.pack_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
+            par.all_gather_bitstreams(payload, cdev)
+        if timed:
+            t_enc += t1 - t0
+            t_dec += t2 - t1
+        last.update(strings=[[b"".join(u[1][0][0] for u in units)], [b"".join(u[1][1][0] for u in units)]], rec=rec)
+
     def step(timed):
         nonlocal t_enc, t_dec
+        if blocks_mode:
+            return step_blocks(timed)
         Q = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)   # fresh maps every step
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -163,7 +191,7 @@ def main():
         elapsed = float(tmax.item())
         ntot = torch.tensor([N], dtype=torch.int64, device=cdev)
         dist.all_reduce(ntot)
-        n_total = int(ntot.item())
+        n_total = N if blocks_mode else int(ntot.item())        # blocks: every rank holds the same frame
     else:
         n_total = N
 
@@ -234,7 +262,12 @@ def main():
         print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "
               f"t_enc {t_enc / args.steps * 1e3:.1f} ms  t_dec {t_dec / args.steps * 1e3:.1f} ms", file=sys.stderr)
 
-    bpp = pcc_amd.utils.count_bits(last["strings"]) / N
+    bits = pcc_amd.utils.count_bits(last["strings"])
+    if blocks_mode and dist is not None:                      # every rank holds a share of the frame's streams
+        bt = torch.tensor([bits], dtype=torch.int64, device=cdev)
+        dist.all_reduce(bt)
+        bits = int(bt.item())
+    bpp = bits / N
     file_mode = None
     if args.file_mode and rank == 0:
         # t_file: the same frame through the container on disk (28-byte header, PCO1 coordinate payload, y, z)
@@ -269,14 +302,16 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if blocks_mode else "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {cfg['grid']}^3 voxel sphere shell r={cfg['radius']}, N={N} points/frame, "
                                "q=(0.5,0.5), configs/Ours.yaml, seeded random weights, in-memory compress+decompress, "
-                               "one frame per rank per step",
-                   "points_per_frame": N, "parallelism": f"frames x{world}" if world > 1 else "single"},
+                               + (f"ONE frame per step cut into {args.block}^3 cubes spread over the ranks by point count"
+                                  if blocks_mode else "one frame per rank per step"),
+                   "points_per_frame": N,
+                   "parallelism": (f"blocks x{world}" if blocks_mode else f"frames x{world}") if world > 1 else "single"},
         "t_enc_ms": t_enc / args.steps * 1e3,
         "t_dec_ms": t_dec / args.steps * 1e3,
         "bpp": bpp,
