@@ -281,6 +281,33 @@ def test_conv_64bit_addressed_fallback_is_bit_identical(pcc):
     assert digests[0] == digests[1]
 
 
+def test_conv_on_operands_beyond_4gib(pcc):
+    """9 M rows x 128 channels = 4.6 GB of features: past the 32-bit buffer offsets, so the dispatch must take
+    the 64-bit-addressed kernel by itself.  Checked on sampled rows against a direct torch evaluation."""
+    rng = np.random.default_rng(33)
+    n = 9_000_000
+    flat = rng.choice(512 ** 3, size=n, replace=False)
+    c = np.stack([np.zeros(n, np.int64), flat // (512 * 512), (flat // 512) % 512, flat % 512], axis=1).astype(np.int32)
+    m = pcc.CoordMap(dev(c), 1, nbatch=1)
+    torch.manual_seed(8)
+    F = torch.randn(n, 128, device=DEV)
+    assert F.numel() * 4 > 0xFFFFF000
+    layer = pcc.MinkowskiConvolution(128, 64, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
+    with torch.no_grad():
+        out = layer(pcc.SparseTensor(F, coordinate_map=m)).F
+        nbr, _, _ = m.kernel_map(m, 3)
+        rows = torch.from_numpy(rng.integers(0, n, size=4096)).to(DEV)
+        W, b = layer.kernel, layer.bias
+        want = b.expand(rows.numel(), -1).clone()
+        for k in range(27):
+            idx = nbr[rows, k].long()
+            ok = (idx >= 0).unsqueeze(1).float()
+            want += (F[idx.clamp(min=0)] * ok) @ W[k]
+    got = out[rows]
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-5 * float(want.abs().max()))
+    del F, out
+
+
 def test_gather_scatter_compact(pcc):
     from pcc_amd import sparse as sp
     rng = np.random.default_rng(2)
