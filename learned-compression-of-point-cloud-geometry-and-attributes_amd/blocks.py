@@ -89,10 +89,11 @@ def prefetch_up_maps(x_map):
     if x_map._cache.get(key):
         return
     dev = x_map.device
-    side = _SIDE_STREAMS.get(dev)
-    if side is None:
-        side = _SIDE_STREAMS[dev] = torch.cuda.Stream(device=dev)
     main = torch.cuda.current_stream(dev)
+    skey = (dev, main.cuda_stream)            # one side stream per main stream (worker threads bring their own)
+    side = _SIDE_STREAMS.get(skey)
+    if side is None:
+        side = _SIDE_STREAMS[skey] = torch.cuda.Stream(device=dev)
     x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
     side.wait_stream(main)
     with torch.cuda.stream(side):

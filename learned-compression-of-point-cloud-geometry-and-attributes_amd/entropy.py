@@ -10,6 +10,8 @@ host at ``update()`` (one-off) and the rANS coder is the host C++ one in the sam
 """
 import math
 
+import threading
+
 import numpy as np
 import scipy.stats
 import torch
@@ -85,6 +87,7 @@ _PINNED = {}
 
 
 def _pinned(key, numel, dtype):
+    key = (threading.get_ident(), key)         # one staging set per worker thread (streamed sequences: one thread per frame in flight)
     buf = _PINNED.get(key)
     if buf is None or buf.numel() < numel or buf.dtype != dtype:
         buf = torch.empty(max(numel, 1), dtype=dtype, pin_memory=True)

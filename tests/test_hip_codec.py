@@ -214,3 +214,52 @@ def test_full_size_frame_properties(pcc, model):
     assert np.unique(keys).size == rec.shape[0]
     col = rec[:, 3:] * 255.0
     assert col.min() >= 0 and col.max() <= 255 and np.abs(col - np.round(col)).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_two_worker_threads_produce_identical_frames(pcc):
+    """streamed sequences (tools/stream_bench.py): two threads, each on its own HIP stream, share one model;
+    every frame must come out bit-identical to the single-threaded result"""
+    import hashlib
+    import threading
+    syn = pcc.synthetic
+    model = syn.make_model(0, "cuda:0")
+    model.update()
+    frames = []
+    for f in range(3):
+        pts = syn.sphere_shell(grid=128, radius=50.0 - f, half_width=0.5)
+        qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+        frames.append((torch.from_numpy(pts).to("cuda:0"), torch.from_numpy(qc).to("cuda:0"), torch.from_numpy(qf).to("cuda:0")))
+
+    def code(i):
+        x, qc, qf = frames[i % 3]
+        Q = pcc.SparseTensor(coordinates=qc, features=qf, device="cuda:0")
+        strings, shape, k, coords = model.compress(x, Q)
+        rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+        h = hashlib.sha256(strings[0][0] + strings[1][0])
+        h.update(rec.cpu().numpy().tobytes())
+        return h.hexdigest()
+
+    want = [code(i) for i in range(3)]
+    got, errs, lock, nxt = {}, [], threading.Lock(), [0]
+
+    def worker():
+        try:
+            s = torch.cuda.Stream(device="cuda:0")
+            with torch.cuda.stream(s):
+                while True:
+                    with lock:
+                        i = nxt[0]
+                        nxt[0] += 1
+                    if i >= 12:
+                        break
+                    got[i] = code(i)
+                s.synchronize()
+        except BaseException as e:          # surfaced below
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker) for _ in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errs, errs
+    assert [got[i] for i in range(12)] == [want[i % 3] for i in range(12)]
