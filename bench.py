@@ -142,7 +142,7 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         if world > 1:
-            payload = b"".join(par.pack_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
+            payload = b"".join(par.pack_items_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
             par.all_gather_bitstreams(payload, cdev)
         if timed:
             t_enc += t1 - t0

@@ -59,14 +59,26 @@ class ColorModel(nn.Module):
 
     # -- model/model.py:95-147 -------------------------------------------------------------------------
     @torch.no_grad()
-    def compress(self, x, Q, path=None):
+    def compress(self, x, Q, path=None, batch=None):
+        """``batch`` (int [N] device tensor, optional; not in the reference's signature): item index per point
+        for the spatial-blocks-as-batch-items mode of SURVEY.md §8e — k and top-k are per item
+        (transforms.py:65-71, blocks.py:130-150), one (y, z) stream pair covers all items; ``k`` then holds
+        one count per item and stage, and ``coordinates`` carries the item index in column 0."""
         N = x.shape[0]
         dev = x.device
-        coords = torch.cat([torch.zeros((N, 1), device=dev, dtype=torch.int32), x[:, :3].to(torch.int32)], dim=1)
+        if batch is None:
+            bcol = torch.zeros((N, 1), device=dev, dtype=torch.int32)
+            nbatch = 1
+        else:
+            if path:
+                raise ValueError("file mode holds one cloud (the 28-byte header has one k per stage)")
+            bcol = batch.to(device=dev, dtype=torch.int32).reshape(N, 1)
+            nbatch = int(bcol.max().item()) + 1
+        coords = torch.cat([bcol, x[:, :3].to(torch.int32)], dim=1)
         feats = torch.cat([torch.ones((N, 1), device=dev, dtype=torch.float32), x[:, 3:6].float()], dim=1)
-        inp = SparseTensor(feats, coordinate_map=CoordMap(coords.contiguous(), 1, nbatch=1))
+        inp = SparseTensor(feats, coordinate_map=CoordMap(coords.contiguous(), 1, nbatch=nbatch))
         if Q.map._nbatch is None:
-            Q.map._nbatch = 1
+            Q.map._nbatch = nbatch
         y, _, k = self.g_a(inp, Q)
         points, strings, shape = self.entropy_model.compress(y)
         coordinates = y.C
@@ -77,19 +89,23 @@ class ColorModel(nn.Module):
 
     # -- model/model.py:152-208 ------------------------------------------------------------------------
     @torch.no_grad()
-    def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None):
+    def decompress(self, path=None, coordinates=None, strings=None, shape=None, k=None, return_batch=False):
+        """``return_batch`` (not in the reference's signature): also return the item index of every decoded
+        point — for streams produced by ``compress(..., batch=...)``."""
         device = self.device
         if path:
             coordinates, strings, shape, k = self.load_bitstream(path)
             coordinates = coordinates.to(device)
             batch = torch.zeros((coordinates.shape[0], 1), device=device, dtype=coordinates.dtype)
             coordinates = torch.cat([batch, coordinates], dim=1)
-        c8 = CoordMap(sp._as_int_coords(coordinates.to(device)), 8, nbatch=1)
+        nbatch = len(k[0]) if isinstance(k[0], (list, tuple)) else 1          # one count per item and stage
+        c8 = CoordMap(sp._as_int_coords(coordinates.to(device)), 8, nbatch=nbatch)
         c32 = c8.down().down()      # coordinates only (g_s.down_conv applied twice, model.py:188-190)
         y_hat, Q_hat = self.entropy_model.decompress([c8, c32], strings, shape)
         x_hat = self.g_s(y_hat, Q_hat, k=k)
         feats = torch.clamp(torch.round(x_hat.F * 255), 0.0, 255.0) / 255
-        return torch.cat([x_hat.C[:, 1:4].to(feats.dtype), feats], dim=1)
+        points = torch.cat([x_hat.C[:, 1:4].to(feats.dtype), feats], dim=1)
+        return (points, x_hat.C[:, 0].clone()) if return_batch else points
 
     # -- container (model/model.py:214-315) --------------------------------------------------------------
     def gpcc_encode(self, points, directory=None):

@@ -81,19 +81,46 @@ def all_gather_bitstreams(payload, device, group=None):
 # ---------------------------------------------------------------------------------------------
 # spatial-block mode: every cube is an independent unit coded by the unmodified single-GPU path
 # ---------------------------------------------------------------------------------------------
-def compress_blocks(model, x, q_feats, block, rank=0, world=1):
+def pack_items_unit(strings, shape, k):
+    """Container of a multi-item unit (compress(..., batch=...)): the reference header cannot hold one k per item,
+    so: >4i [N_z, len_y, len_z, n_items], then 3 * n_items big-endian int32 counts (stage-major), y, z."""
+    n_items = len(k[0])
+    flat = [int(v) for stage in k for v in stage]
+    hdr = struct.pack(">4i", int(shape[0]), len(strings[0][0]), len(strings[1][0]), n_items)
+    return hdr + struct.pack(">%di" % len(flat), *flat) + strings[0][0] + strings[1][0]
+
+
+def compress_blocks(model, x, q_feats, block, rank=0, world=1, batched=True):
     """Code the cubes of edge ``block`` assigned to ``rank``.
 
     x: float [N, 6] device tensor (xyz voxel coordinates + rgb), q_feats: [N, 2] (q_g, q_a).
     Coordinates stay absolute (stride alignment is the whole-frame one).  Returns
-    (block ids [M,3], assignment, units) with units = [(block index, strings, shape, k, coords8)].
+    (block ids [M,3], assignment, units).
+
+    batched (default): the rank's cubes are the batch items of ONE compress call (the
+    model counts k and selects top-k per item) -> one unit (block indices, strings, shape, k, coords8 with the
+    item index in column 0).  Kernels then see all of the rank's points at once instead of one small cube at a
+    time.  batched=False: one call and one unit (block index, strings, shape, k, coords8) per cube.
     """
     from .sparse import SparseTensor
     xyz = x[:, :3].detach().cpu().numpy()
     ids, rows = split_blocks(xyz, block)
     parts = assign_blocks([len(r) for r in rows], world)
     units = []
-    for b in parts[rank]:
+    mine = parts[rank]
+    if batched:
+        if mine:
+            sel_np = np.concatenate([rows[b] for b in mine])
+            item = np.concatenate([np.full(len(rows[b]), i, dtype=np.int32) for i, b in enumerate(mine)])
+            sel = torch.from_numpy(sel_np).to(x.device)
+            bt = torch.from_numpy(item).to(x.device)
+            xb = x.index_select(0, sel)
+            qc = torch.cat([bt.reshape(-1, 1).to(xb.dtype), xb[:, :3]], dim=1)
+            Q = SparseTensor(coordinates=qc, features=q_feats.index_select(0, sel), device=x.device, nbatch=len(mine))
+            strings, shape, k, coords = model.compress(xb, Q, batch=bt)
+            units.append((list(mine), strings, shape, k, coords))
+        return ids, parts, units
+    for b in mine:
         sel = torch.from_numpy(rows[b]).to(x.device)
         xb = x.index_select(0, sel)
         qc = torch.cat([torch.zeros((xb.shape[0], 1), device=x.device), xb[:, :3]], dim=1)

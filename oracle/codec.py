@@ -197,15 +197,19 @@ class Codec:
         return self.eb.aux_loss()
 
     # -- model.py:95-147 -------------------------------------------------------------
-    def compress(self, x, Q_coords, Q_feats):
+    def compress(self, x, Q_coords, Q_feats, batch=None):
         """x: float [N,6]; q-map given as coords [N,4] (batch first) + feats [N,2].
 
-        Returns (strings, shape, k, coordinates) like the in-memory API.
+        Returns (strings, shape, k, coordinates) like the in-memory API.  ``batch`` (int [N], optional):
+        item index of every point — the spatial-blocks-as-batch-items mode of SURVEY.md §8e: the model
+        already counts k and selects top-k per item (transforms.py:65-71, blocks.py:130-150); one
+        (y, z) stream pair covers all items in canonical (b, x, y, z) order.
         """
         assert self.updated, "call update() first (evaluate.py:80-84)"
         x = np.asarray(x, dtype=np.float32)
         N = x.shape[0]
-        pts = np.concatenate([np.zeros((N, 1), np.float32), x[:, :3]], axis=1).astype(np.int32)
+        bcol = np.zeros((N, 1), np.float32) if batch is None else np.asarray(batch, dtype=np.float32).reshape(N, 1)
+        pts = np.concatenate([bcol, x[:, :3]], axis=1).astype(np.int32)
         feats = torch.from_numpy(np.concatenate([np.ones((N, 1), np.float32), x[:, 3:6]], axis=1))
         inp = SparseTensor(pts, feats, 1)
         Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
@@ -251,6 +255,7 @@ class Codec:
         x_hat = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k)
         feats = torch.clamp(torch.round(x_hat.F * 255), 0.0, 255.0) / 255
         self.last_dec = dict(y_hat=y_hat, Q_hat=Q_hat, x_hat=x_hat)
+        self.last_batch = x_hat.C[:, 0].copy()
         return np.concatenate([x_hat.C[:, 1:4].astype(np.float32), feats.numpy()], axis=1)
 
     # -- model.py:51-93 (eval mode) --------------------------------------------------

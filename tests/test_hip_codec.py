@@ -145,8 +145,8 @@ def test_block_partition_mode_vs_oracle_with_same_partition(pcc, model, oracle_c
     cfg = dict(grid=64, radius=27.0, half_width=0.6)
     pts, qc, qf = _inputs(pcc, cfg)
     x = torch.from_numpy(pts).to(DEV)
-    ids, parts, units0 = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=0, world=2)
-    _, _, units1 = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=1, world=2)
+    ids, parts, units0 = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=0, world=2, batched=False)
+    _, _, units1 = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=1, world=2, batched=False)
     assert sorted(parts[0] + parts[1]) == list(range(len(ids))) and len(ids) == 8
     units = sorted(units0 + units1, key=lambda u: u[0])
     rec = par.decompress_blocks(model, units).cpu().numpy()
@@ -167,6 +167,40 @@ def test_block_partition_mode_vs_oracle_with_same_partition(pcc, model, oracle_c
     assert abs(bits - o_bits) <= 3e-3 * o_bits + 64
     m, om = pc_metrics(pts, rec), pc_metrics(pts, o_rec)
     assert abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]) <= 2e-2 and abs(m["sym_y_psnr"] - om["sym_y_psnr"]) <= 2e-2
+
+
+def test_blocks_as_batch_items_vs_oracle(pcc, model, oracle_codec):
+    """SURVEY §8e option 2 as the reference's batch mechanism: a rank's cubes are the items of ONE compress call
+    (per-item k and top-k, one stream pair).  Parity target = the oracle run on the same items."""
+    from pcc_amd import parallel as par
+    cfg = dict(grid=64, radius=27.0, half_width=0.6)
+    pts, qc, qf = _inputs(pcc, cfg)
+    x = torch.from_numpy(pts).to(DEV)
+    ids, parts, units = par.compress_blocks(model, x, torch.from_numpy(qf).to(DEV), 32, rank=1, world=2, batched=True)
+    assert len(units) == 1 and len(parts[1]) == 4
+    blocks, strings, shape, k, coords = units[0]
+    assert all(len(stage) == len(blocks) for stage in k)                       # one count per item and stage
+    rec, rec_item = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k, return_batch=True)
+    rec, rec_item = rec.cpu().numpy(), rec_item.cpu().numpy()
+    _, rows = par.split_blocks(pts, 32)
+    sel = np.concatenate([rows[b] for b in blocks])
+    item = np.concatenate([np.full(len(rows[b]), i) for i, b in enumerate(blocks)])
+    sub = pts[sel]
+    o_qc = np.concatenate([item.reshape(-1, 1).astype(np.float32), sub[:, :3]], axis=1)
+    o_strings, o_shape, o_k, o_coords = oracle_codec.compress(sub, o_qc, qf[sel], batch=item)
+    assert shape == o_shape and k == o_k
+    assert set(map(tuple, coords.cpu().numpy().tolist())) == set(map(tuple, o_coords.tolist()))
+    o_bits, bits = count_bits(o_strings), count_bits(strings)
+    assert abs(bits - o_bits) <= 3e-3 * o_bits + 64
+    o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+    assert rec.shape == o_rec.shape == (sub.shape[0], 6)
+    for i in range(len(blocks)):                                                # every item decodes to its own count
+        assert int((rec_item == i).sum()) == len(rows[blocks[i]])
+    m, om = pc_metrics(sub, rec), pc_metrics(sub, o_rec)
+    assert abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]) <= 2e-2 and abs(m["sym_y_psnr"] - om["sym_y_psnr"]) <= 2e-2
+    with pytest.raises(ValueError):
+        Q = pcc.SparseTensor(coordinates=torch.from_numpy(o_qc).to(DEV), features=torch.from_numpy(qf[sel]).to(DEV), device=DEV)
+        model.compress(torch.from_numpy(sub).to(DEV), Q, path="/tmp/never_written.bin", batch=torch.from_numpy(item).to(DEV))
 
 
 @pytest.mark.parametrize("n_pts", [1, 7, 70])
