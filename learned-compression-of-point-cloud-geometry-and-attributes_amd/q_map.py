@@ -5,8 +5,8 @@ A quality map is a sparse tensor on the frame's coordinates with two channels ``
 batch item, either a linear gradient along a random axis or a uniform map with random levels — the
 reference's training-time generator, driven by Python's ``random`` like the reference so that a
 seeded run draws the same maps — and returns it together with the lambda map used by the losses.
-``uniform_map`` / ``gradient_map`` build the fixed maps of the evaluation scripts
-(utils.py:436-445, evaluate_view_dep.py:209-260).  Elementwise work on [N, 2] tensors; plain torch.
+``uniform_map`` / ``gradient_map`` / ``view_dependent_map`` / ``roi_map`` build the fixed maps of the
+evaluation scripts (utils.py:436-445, evaluate_view_dep.py:207-260).  Elementwise work on [N, 2] tensors; plain torch.
 """
 import math
 import random
@@ -30,6 +30,20 @@ def gradient_map(coords_map, axis, lo=0.0, hi=1.0):
     t = torch.clamp((c - c.min()) / (c.max() - c.min() + 1e-10), 0, 1)
     q = lo + (hi - lo) * t
     return SparseTensor(q.unsqueeze(1).repeat(1, 2).contiguous(), coordinate_map=coords_map)
+
+
+def view_dependent_map(coords_map, q_g, q_a, axis, lo, hi):
+    """evaluate_view_dep.py:207-215: quality falls off along a viewing axis — score = clip((p[axis] - lo) /
+    (hi - lo), 0, 1), channels [q_g * score, q_a * score]"""
+    c = coords_map.coords[:, axis].to(torch.float32)
+    score = torch.clamp((c - float(lo)) / (float(hi) - float(lo)), 0, 1)
+    return SparseTensor(torch.stack([float(q_g) * score, float(q_a) * score], dim=1).contiguous(), coordinate_map=coords_map)
+
+
+def roi_map(coords_map, q_g, q_a, axis, plane):
+    """evaluate_view_dep.py:254-260: region of interest — full quality where p[axis] >= plane, zero below"""
+    score = (coords_map.coords[:, axis] >= plane).to(torch.float32)
+    return SparseTensor(torch.stack([float(q_g) * score, float(q_a) * score], dim=1).contiguous(), coordinate_map=coords_map)
 
 
 class Q_Map:

@@ -84,6 +84,12 @@ def test_q_map_generator_and_lambda_scaling(pcc):
     assert torch.allclose(lam2.F[:, 1].cpu(), want[:, 1] ** 2 * (12800 - 100) + 100, rtol=1e-5)
     g = qm.gradient_map(geom.map, 2, 0.1, 0.9)
     assert float(g.F.min()) == pytest.approx(0.1, abs=1e-6) and float(g.F.max()) == pytest.approx(0.9, abs=1e-6)
+    v = qm.view_dependent_map(geom.map, 0.4, 0.8, 1, 10, 50)
+    x1 = geom.C[:, 1].float().cpu()
+    assert torch.allclose(v.F[:, 1].cpu(), 0.8 * torch.clamp((x1 - 10) / 40, 0, 1), atol=1e-6)
+    r = qm.roi_map(geom.map, 0.4, 0.8, 3, 32)
+    z = geom.C[:, 3].cpu()
+    assert torch.equal(r.F[:, 0].cpu() > 0, z >= 32) and float(r.F[:, 0].max()) == pytest.approx(0.4)
     with pytest.raises(ValueError):
         qm.Q_Map({"mode": "linear"})
 
