@@ -135,6 +135,17 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
                  const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
                  int32_t act, const float* film, const float* residual, void* stream);
 
+/* bf16-input variant of pcc_conv_fwd (training / BASELINE config 5): features and packed weights are bf16
+ * (fin [n_in, cin] bf16, cin a multiple of 64; pcc_conv_pack_weights_bf16: [K, cin/8, cout^32, 8]), products
+ * accumulate in fp32 on v_mfma_f32_32x32x16_bf16, bias / FiLM / activation / residual and the output are fp32.
+ * Same tiling, row order, offset skipping and accumulation order as the fp32 kernel; half the gather bytes
+ * and 1/8 of the MFMA time per channel.  NOT used by compress / decompress (fp32 parity budget). */
+int64_t pcc_conv_packed_elems_bf16(int32_t K, int32_t cin, int32_t cout);
+int pcc_conv_pack_weights_bf16(const float* w, int32_t K, int32_t cin, int32_t cout, uint16_t* w_packed, void* stream);
+int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint16_t* w_packed, const float* bias,
+                      const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
+                      int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
+
 /* Narrow-head convolution, second half (cout <= 4 on wide inputs: the occupancy logit of
  * model/blocks.py:94-98,142 and the q-map heads).  The caller first computes
  * scores[i, k*cout + c] = in[i] . W[k][:, c] for every INPUT row with one kernel_size-1 call of

@@ -24,6 +24,7 @@ namespace pcc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct ConvArgs {
     const float* fin;
@@ -38,6 +39,7 @@ struct ConvArgs {
     const float* residual;  // [n_out, cout] or null
     int64_t n_in, n_out;
     int cin, cout, coutp, K, act;
+    int bf16;    // buffer kernel: fin / wp hold bf16 (pcc_conv_fwd_bf16); accumulation and output stay fp32
     int debug;   // development ablations of conv_mfma_kernel, compiled in only with -DPCC_CONV_ABLATE (PCC_CONV_DEBUG): 1 no DMA, 4 no barrier, 8 no MFMA, 16 no A DMA, 32 no W DMA
 };
 
@@ -62,6 +64,22 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         const int k = (int)(t / (cinp / 4));
         const int ci = 4 * g + s;
         wp[e] = (ci < cin && col < cout) ? w[((int64_t)k * cin + ci) * cout + col] : 0.0f;
+    }
+}
+
+// bf16 packing: Wp[k][g][col][j] = bf16(W[k][8g+j][col]), zero padded to cinp (x64) and coutp (x32)
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, int K, int cin, int cout,
+                                                                int cinp, int coutp, __bf16* __restrict__ wp) {
+    const int64_t total = (int64_t)K * cinp * coutp;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7);
+        int64_t t = e >> 3;
+        const int col = (int)(t % coutp);
+        t /= coutp;
+        const int g = (int)(t % (cinp / 8));
+        const int k = (int)(t / (cinp / 8));
+        const int ci = 8 * g + j;
+        wp[e] = (__bf16)((ci < cin && col < cout) ? w[((int64_t)k * cin + ci) * cout + col] : 0.0f);
     }
 }
 
@@ -374,7 +392,7 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false>
 __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)           // the buffer builtins exist in the device pass only; the host pass needs just the stub
     constexpr int RPT = BM / 32;              // gather DMAs per thread and step (8 lanes per row)
@@ -384,6 +402,10 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
     constexpr int W_ELEMS = 8 * BN * 4;
     constexpr int W_LOADS = (8 * BN) / 256;
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && MT <= 2 && NT >= 1 && W_LOADS >= 1, "bad tiling");
+    // BF16: the same byte images — a step is 64 bf16 channels (128 B per gathered row, 8 groups of 8 channels per
+    // weight column) instead of 32 floats, and each 16-B fragment feeds ONE v_mfma_f32_32x32x16_bf16 (8 k-values
+    // per lane) instead of four v_mfma_f32_32x32x2_f32.  CCH then counts 64-channel chunks.
+    constexpr int ESZ = BF16 ? 2 : 4;
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;
@@ -433,9 +455,9 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 
     if (tmask != 0u) {
         __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 4), BUF_FLAGS);
+            const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * ESZ), BUF_FLAGS);
         __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.wp), 0, (int)((uint32_t)K * a.cin * a.coutp * 4), BUF_FLAGS);
+            const_cast<float*>(a.wp), 0, (int)((uint32_t)K * a.cin * a.coutp * ESZ), BUF_FLAGS);
         __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<int32_t*>(a.nbr), 0, HAS_NBR ? (int)(uint32_t)(a.n_out * K * 4) : 0, BUF_FLAGS);
 
@@ -463,9 +485,9 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             w_voff[j] = (uint32_t)((g * a.coutp + nt * BN + col) * 16);
         }
         const int wave_u = __builtin_amdgcn_readfirstlane(wid);
-        const uint32_t w_kstride = (uint32_t)(a.cin / 4) * a.coutp * 16;   // bytes per kernel offset
+        const uint32_t w_kstride = (uint32_t)(a.cin * ESZ / 16) * a.coutp * 16;   // bytes per kernel offset (16-B channel groups)
         const uint32_t w_cstride = (uint32_t)8 * a.coutp * 16;             // bytes per 32-channel chunk
-        const uint32_t a_row_bytes = (uint32_t)a.cin * 4;
+        const uint32_t a_row_bytes = (uint32_t)a.cin * ESZ;
 
         auto load_idx = [&](int k) {
             if constexpr (HAS_NBR) {
@@ -528,14 +550,24 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 #pragma unroll
                     for (int n = 0; n < NT; ++n) bv[nb][n] = lds4(w_addr[buf] + (2 * (kk + 1) * BN + 32 * n) * 16);
                 }
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
+                if constexpr (BF16) {
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NT; ++n)
                             if ((LIVE >> m) & 1u)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[cb][m]),
+                                                                                    __builtin_bit_cast(bf16x8, bv[cb][n]), acc[m][n], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int m = 0; m < MT; ++m)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+                                if ((LIVE >> m) & 1u)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cb][m][s], bv[cb][n][s], acc[m][n], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_s_setprio(0);
         };
@@ -715,10 +747,10 @@ static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     return PCC_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false>
 static int launch_mfma_buf_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR>;
+    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16>;
     const int lds = conv_lds_bytes<BM, BN>();
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -755,6 +787,21 @@ static int launch_mfma(const ConvArgs& a, hipStream_t st) {
 #undef PCC_BUF_CASE
     }
     return a.nbr ? launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, true>(a, st) : launch_mfma_impl<BM, BN, WAVES_M, WAVES_N, false>(a, st);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_mfma_bf16(const ConvArgs& a, hipStream_t st) {
+#define PCC_BF16_CASE(C)                                                                                       \
+    case C:                                                                                                    \
+        return a.nbr ? launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, C, true, true>(a, st)                    \
+                     : launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, C, false, true>(a, st);
+    switch (a.cin / 64) {
+        PCC_BF16_CASE(1) PCC_BF16_CASE(2) PCC_BF16_CASE(3) PCC_BF16_CASE(4)
+        default: break;
+    }
+#undef PCC_BF16_CASE
+    pcc::set_error("pcc_conv_fwd_bf16: cin=%d not supported (multiples of 64 up to 256)", a.cin);
+    return PCC_ERR_UNSUPPORTED;
 }
 
 template <int CIN>
@@ -794,6 +841,44 @@ int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, 
     return PCC_OK;
 }
 
+int64_t pcc_conv_packed_elems_bf16(int32_t K, int32_t cin, int32_t cout) {
+    return (int64_t)K * ((cin + 63) / 64 * 64) * round_up32(cout);
+}
+
+int pcc_conv_pack_weights_bf16(const float* w, int32_t K, int32_t cin, int32_t cout, uint16_t* w_packed, void* stream) {
+    PCC_REQUIRE(K >= 1 && cin >= 1 && cout >= 1, "pcc_conv_pack_weights_bf16: bad shape");
+    const int cinp = (cin + 63) / 64 * 64, coutp = round_up32(cout);
+    const int64_t total = (int64_t)K * cinp * coutp;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), w, K, cin,
+                       cout, cinp, coutp, reinterpret_cast<__bf16*>(w_packed));
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint16_t* w_packed, const float* bias, const int32_t* nbr,
+                      const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
+                      int32_t act, const float* film, const float* residual, void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd_bf16: K=%d out of range", K);
+    PCC_REQUIRE(cin % 64 == 0 && cin <= 256, "pcc_conv_fwd_bf16: cin must be a multiple of 64 up to 256 (got %d)", cin);
+    PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd_bf16: nbr == NULL needs K == 1 and n_in == n_out");
+    PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd_bf16: bad activation %d", act);
+    PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd_bf16: packed weights required");
+    if (n_out <= 0) return PCC_OK;
+    ConvArgs a;
+    a.fin = reinterpret_cast<const float*>(fin); a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
+    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout; a.film = film; a.residual = residual;
+    a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 1;
+    a.debug = 0;
+    PCC_REQUIRE((uint64_t)n_in * cin * 2 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB,
+                "pcc_conv_fwd_bf16: operands of 4 GiB and more are not supported");
+    hipStream_t st = as_stream(stream);
+    const int64_t wgs128 = ((a.n_out + 63) / 64) * (a.coutp / 128);
+    if (a.coutp % 128 == 0 && wgs128 < 768) return launch_mfma_bf16<64, 64, 2, 2>(a, st);
+    if (a.coutp % 128 == 0) return launch_mfma_bf16<64, 128, 2, 2>(a, st);
+    if (a.coutp % 64 == 0) return launch_mfma_bf16<128, 64, 2, 2>(a, st);
+    return launch_mfma_bf16<128, 32, 4, 1>(a, st);
+}
+
 int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int32_t K, int32_t cout, const float* bias,
                        float* out, int64_t n_out, int32_t act, void* stream) {
     PCC_REQUIRE(K >= 1 && K <= 27 && cout >= 1 && ld >= K * cout, "pcc_gather_sum_fwd: bad shape (K=%d cout=%d ld=%d)", K, cout, ld);
@@ -817,7 +902,7 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
     ConvArgs a;
     a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout;
     a.film = film; a.residual = residual; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout;
-    a.coutp = round_up32(cout); a.K = K; a.act = act;
+    a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("PCC_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     hipStream_t st = as_stream(stream);
     if (cin % 32 == 0) {
