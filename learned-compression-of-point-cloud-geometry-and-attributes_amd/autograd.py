@@ -11,12 +11,25 @@ in model/, driven by train.py:194-206).  Here one ``torch.autograd.Function`` wr
 Activations, FiLM and residuals — fused into the convolution's epilogue on the inference path — are
 ordinary torch ops here so that autograd differentiates them.
 """
+import os
+
 import torch
 
 from . import _lib
 from ._lib import check, ptr
 
 _THIN_CIN = (1, 2, 4, 8, 16)
+
+# bf16 compute for the training path (BASELINE config 5: "bf16"): convolutions whose input width is a multiple of
+# 64 cast their input (forward: the features; backward-data: the output gradient) and weights to bf16 and run on
+# v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 outputs; everything else — narrow and thin layers,
+# the weight gradient, the entropy models, the losses, the master weights — stays fp32.  Off by default.
+BF16 = os.environ.get("PCC_TRAIN_BF16", "0") == "1"
+
+
+def set_bf16(enabled):
+    global BF16
+    BF16 = bool(enabled)
 
 
 def _packed(w):
@@ -34,6 +47,13 @@ def _launch_conv(feats, w, bias, nbr, order, gmask, n_out):
     L = _lib.lib()
     K, cin, cout = w.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if BF16 and cin % 64 == 0 and feats.shape[0] * cin * 2 < 0xFFFFF000:
+        wp = torch.empty(L.pcc_conv_packed_elems_bf16(K, cin, cout), dtype=torch.bfloat16, device=feats.device)
+        check(L.pcc_conv_pack_weights_bf16(ptr(w), K, cin, cout, ptr(wp), _lib.stream()))
+        x = feats.to(torch.bfloat16)
+        check(L.pcc_conv_fwd_bf16(ptr(x), feats.shape[0], cin, ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K, ptr(out),
+                                  n_out, cout, 0, None, None, _lib.stream()))
+        return out
     check(L.pcc_conv_fwd(ptr(feats), feats.shape[0], cin, ptr(w), ptr(_packed(w)), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
                          ptr(out), n_out, cout, 0, None, None, _lib.stream()))
     return out

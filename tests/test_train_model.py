@@ -184,3 +184,36 @@ def test_training_step_batch_of_two_matches_oracle(pcc):
     errs.sort(reverse=True)
     assert errs[0][0] < 5e-2, errs[:3]
     assert sum(1 for e, _ in errs if e > 5e-3) <= 3, errs[:6]
+
+
+def test_bf16_compute_tracks_the_fp32_training_step(pcc):
+    """BASELINE config 5's precision: bf16 operands on the wide convolutions (forward and backward-data), fp32
+    accumulation, weight gradients, entropy models and losses.  Same noise, same data: the loss terms stay within
+    2 % and the gradient keeps its direction."""
+    from pcc_amd import autograd as ag, entropy as pe
+    from pcc_amd.loss import OURS_LOSS, Loss
+    model, pts, qc, qf, lam = _setup(pcc)
+    model.train()
+    coords = torch.from_numpy(qc).to(DEV)
+    inp = pcc.SparseTensor(coordinates=coords, features=torch.from_numpy(pts[:, 3:]).to(DEV), device=DEV)
+    Q = pcc.SparseTensor(torch.from_numpy(qf).to(DEV), coordinate_map=inp.map)
+    Lam = pcc.SparseTensor(torch.from_numpy(lam).to(DEV), coordinate_map=inp.map)
+    res = {}
+    for mode in (False, True):
+        ag.set_bf16(mode)
+        pe.NOISE_SOURCE = coord_noise
+        try:
+            model.zero_grad(set_to_none=True)
+            total, parts = Loss(OURS_LOSS)(inp, model(inp, Q, Lam))
+            total.backward()
+        finally:
+            pe.NOISE_SOURCE = None
+            ag.set_bf16(False)
+        grads = torch.cat([p.grad.reshape(-1) for n, p in model.named_parameters() if p.grad is not None and not n.endswith("quantiles")])
+        res[mode] = ({k: float(v.detach()) for k, v in parts.items()}, grads.clone())
+    for key in res[False][0]:
+        assert res[True][0][key] == pytest.approx(res[False][0][key], rel=2e-2), key
+    g32, g16 = res[False][1], res[True][1]
+    cos = float(torch.dot(g32, g16) / (g32.norm() * g16.norm()))
+    assert cos > 0.99, cos
+    assert float((g32 - g16).norm() / g32.norm()) < 0.15

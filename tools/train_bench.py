@@ -88,7 +88,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "training points/sec", "value": npts / el, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                           "ms_per_step": el / args.steps * 1e3, "batch_cubes_per_gpu": args.batch, "block": args.block,
-                          "points_per_step": npts / args.steps, "dtype": "f32", "last_loss": last, "data": "synthetic"}))
+                          "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
 
