@@ -215,6 +215,10 @@ int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout);
 int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy, int64_t n_out, int32_t cout,
                    const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* dw,
                    float* scratch, int64_t scratch_elems, void* stream);
+/* bf16 operands (fin, dy bf16; cin, cout multiples of 64), fp32 accumulation and result; same scratch size. */
+int pcc_conv_wgrad_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint16_t* dy, int64_t n_out, int32_t cout,
+                        const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* dw,
+                        float* scratch, int64_t scratch_elems, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Latent-coordinate side channel of file mode.  Replaces ColorModel.gpcc_encode / gpcc_decode

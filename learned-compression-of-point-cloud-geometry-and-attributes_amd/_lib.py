@@ -53,6 +53,8 @@ SIGNATURES = {
     "pcc_conv_wgrad_scratch_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "pcc_conv_wgrad": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
                                c_i64, c_void_p]),
+    "pcc_conv_wgrad_bf16": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_void_p,
+                                    c_i64, c_void_p]),
     "pcc_octree_scratch_bytes": (c_i64, [c_i64]),
     "pcc_octree_occupancy": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_octree_expand": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),

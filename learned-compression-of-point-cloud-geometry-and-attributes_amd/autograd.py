@@ -23,7 +23,8 @@ _THIN_CIN = (1, 2, 4, 8, 16)
 # bf16 compute for the training path (BASELINE config 5: "bf16"): convolutions whose input width is a multiple of
 # 64 cast their input (forward: the features; backward-data: the output gradient) and weights to bf16 and run on
 # v_mfma_f32_32x32x16_bf16 with fp32 accumulation and fp32 outputs; everything else — narrow and thin layers,
-# the weight gradient, the entropy models, the losses, the master weights — stays fp32.  Off by default.
+# the entropy models, the losses, the master weights — stays fp32; weight gradients of layers with both widths
+# multiples of 64 take bf16 operands too (fp32 sums).  Off by default.
 BF16 = os.environ.get("PCC_TRAIN_BF16", "0") == "1"
 
 
@@ -139,8 +140,13 @@ class SparseConvFn(torch.autograd.Function):
             dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
             ne = L.pcc_conv_wgrad_scratch_elems(K, cin, cout)
             scratch = torch.empty(ne, dtype=torch.float32, device=dev)
-            check(L.pcc_conv_wgrad(ptr(feats), n_in, cin, ptr(dy), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw), ptr(scratch),
-                                   ne, _lib.stream()))
+            if BF16 and cin % 64 == 0 and cout % 64 == 0 and max(n_in * cin, n_out * cout) * 2 < 0xFFFFF000:
+                xb, gb = feats.to(torch.bfloat16), dy.to(torch.bfloat16)
+                check(L.pcc_conv_wgrad_bf16(ptr(xb), n_in, cin, ptr(gb), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
+                                            ptr(scratch), ne, _lib.stream()))
+            else:
+                check(L.pcc_conv_wgrad(ptr(feats), n_in, cin, ptr(dy), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
+                                       ptr(scratch), ne, _lib.stream()))
             if out_channels is not None:
                 full = torch.zeros((K, cin, kshape[-1]), dtype=torch.float32, device=dev)
                 full[:, :, :out_channels] = dw

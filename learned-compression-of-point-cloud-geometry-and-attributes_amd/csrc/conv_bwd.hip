@@ -161,6 +161,124 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #endif
 }
 
+// bf16 operands (pcc_conv_wgrad_bf16; cin, cout multiples of 64): X and dY are bf16, products accumulate in fp32 on
+// v_mfma_f32_32x32x16_bf16.  The GEMM's K dimension is the ROWS, but the LDS images are [row][64 channels]
+// (128-B rows, what the 16-B-per-lane LDS-DMA produces), so a lane's 8 consecutive k-values of one channel are 8
+// two-byte reads 128 B apart — the operand transpose is paid in ds_read_u16 instructions instead of a second
+// staging pass.  The kernel is gather-bound like the bf16 forward, the extra LDS instructions hide under it.
+// A workgroup owns offset k, a block of up to 128 x 128 of W[k] = TM x TN tiles of 32 x 32 dealt round-robin to the
+// four waves (128 x 128: a wave holds one column of 4 tiles and reads its dY operand once), and every SPLIT-th
+// group of 32 rows (two MFMA k-steps).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);             // [2 chunks][32 rows][64 ch]
+    unsigned short* Bs = As + 2 * 2048;                                       // [2 chunks][32 rows][64 co]
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    const int SPLIT = a.split;
+    const int k = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
+    const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
+    const int cbi = min(2, (a.cin - cin0) / 64), cbo = min(2, (a.cout - cout0) / 64);     // 64-channel chunks present
+    const int TM = 2 * cbi, TN = 2 * cbo, NTILES = TM * TN;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[i][j] = 0.0f;
+
+    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 2), WG_FLAGS);
+    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(uint32_t)(a.n_out * a.cout * 2), WG_FLAGS);
+    const int64_t ng = (a.n_out + 31) >> 5;
+    const int slot = lane & 7, rsub = lane >> 3;
+    // staging roles: waves 0-1 the X chunks 0-1, waves 2-3 the dY chunks 0-1
+    const bool stage_x = wave_u < 2;
+    const int cw = wave_u & 1;
+    // my tiles: t = wave, wave + 4, ...; tile t -> (m = t / TN, n = t % TN)
+    int tm[4], tn[4];
+    bool live[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int tt = wave_u + 4 * i;
+        live[i] = tt < NTILES;
+        tm[i] = live[i] ? tt / TN : 0;
+        tn[i] = live[i] ? tt % TN : 0;
+    }
+
+    for (int64_t gbase = s; gbase < ng; gbase += 64 * SPLIT) {
+      const int64_t gmine = gbase + (int64_t)lane * SPLIT;
+      const uint32_t gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
+      unsigned long long todo = __ballot((gml >> k) & 1u);
+      while (todo) {
+        const int bit = __ffsll(todo) - 1;
+        todo &= todo - 1;
+        const int64_t g = gbase + (int64_t)bit * SPLIT;
+        uint32_t vo[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t pos = g * 32 + 8 * i + rsub;
+            const bool ok = pos < a.n_out;
+            if (stage_x) {
+                const int idx = ok ? a.nbr[pos * a.K + k] : -1;
+                vo[i] = (idx >= 0 && cw < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 2) + (uint32_t)((cin0 + cw * 64) * 2 + slot * 16) : WG_OOB;
+            } else {
+                const int64_t row = ok ? (a.order ? a.order[pos] : pos) : 0;
+                vo[i] = (ok && cw < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 2) + (uint32_t)((cout0 + cw * 64) * 2 + slot * 16) : WG_OOB;
+            }
+        }
+        unsigned short* dst = (stage_x ? As : Bs) + cw * 2048;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (stage_x) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(dst + i * 512), 16, vo[i], 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(dst + i * 512), 16, vo[i], 0, 0, 0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {                       // rows 16 ks + 8 h + j
+            const int row0 = 16 * ks + 8 * h;
+            bf16x8 bop[4];
+            int bn_loaded = -1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (!live[i]) continue;
+                // operand of tile i: 8 rows of one channel, 128 B apart
+                const unsigned short* ap = As + (tm[i] >> 1) * 2048 + row0 * 64 + (tm[i] & 1) * 32 + r;
+                unsigned short av[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) av[j] = ap[j * 64];
+                if (tn[i] != bn_loaded) {                      // 128 x 128: all of the wave's tiles share n
+                    const unsigned short* bp = Bs + (tn[i] >> 1) * 2048 + row0 * 64 + (tn[i] & 1) * 32 + r;
+                    unsigned short bv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bv[j] = bp[j * 64];
+                    bop[0] = __builtin_bit_cast(bf16x8, bv);
+                    bn_loaded = tn[i];
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bop[0], acc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+      }
+    }
+
+    float* P = a.partial + ((int64_t)s * a.K + k) * a.cin * a.cout;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (!live[i]) continue;
+        const int co = cout0 + tn[i] * 32 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = cin0 + tm[i] * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            P[(int64_t)ci * a.cout + co] = acc[i][reg];
+        }
+    }
+#endif
+}
+
 // thin shapes (cin or cout not a multiple of 32: q-map branches, input layer, narrow heads): cin * cout <= 4096.
 // One workgroup per (offset, split).  With >= 256 (ci, co) pairs a thread owns up to 16 pairs and walks the
 // split's rows; with fewer pairs (64 -> 1: the occupancy head on 5 M candidates) the spare threads take
@@ -283,6 +401,31 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
     }
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems,
                        wgrad_partials(cin, cout, a.split), dw);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_conv_wgrad_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint16_t* dy, int64_t n_out, int32_t cout,
+                        const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* dw, float* scratch,
+                        int64_t scratch_elems, void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_wgrad_bf16: bad K");
+    PCC_REQUIRE(cin % 64 == 0 && cout % 64 == 0 && cin >= 64 && cout >= 64, "pcc_conv_wgrad_bf16: cin and cout must be multiples of 64 (got %d, %d)", cin, cout);
+    PCC_REQUIRE(nbr != nullptr, "pcc_conv_wgrad_bf16: neighbour table required");
+    PCC_REQUIRE((uint64_t)n_in * cin * 2 <= WG_OOB && (uint64_t)n_out * cout * 2 <= WG_OOB, "pcc_conv_wgrad_bf16: operands of 4 GiB and more are not supported");
+    hipStream_t st = as_stream(stream);
+    const int64_t elems = (int64_t)K * cin * cout;
+    if (n_out <= 0) {
+        PCC_CHECK_HIP(hipMemsetAsync(dw, 0, (size_t)elems * sizeof(float), st));
+        return PCC_OK;
+    }
+    WgradArgs a;
+    a.fin = reinterpret_cast<const float*>(fin); a.dy = reinterpret_cast<const float*>(dy); a.nbr = nbr; a.order = order;
+    a.gmask = group_mask32; a.partial = scratch; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.K = K;
+    a.split = wgrad_splits(n_out);
+    PCC_REQUIRE(scratch_elems >= (int64_t)a.split * elems, "pcc_conv_wgrad_bf16: scratch too small");
+    const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
+    hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), 4 * 2048 * sizeof(unsigned short), st, a);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, a.split, dw);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -51,3 +51,31 @@ def test_bf16_conv_matches_fp32_on_rounded_operands(pcc, cin, cout, ksize):
     # and it is close to the unrounded fp32 convolution at bf16 precision
     full = (F @ W[0] + b) if ksize == 1 else on._apply_conv(F, W, b.reshape(1, -1), oc.kernel_map(c, c, ksize, 1), n)
     assert float((got - full).abs().max()) < 3e-2 * float(full.abs().max())
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 64), (128, 128), (128, 64), (64, 128), (192, 256), (256, 64)])
+def test_bf16_weight_gradient_matches_fp32_on_rounded_operands(pcc, cin, cout):
+    from pcc_amd import _lib
+    from pcc_amd._lib import check, ptr
+    L = pcc.lib()
+    torch.manual_seed(cin * 3 + cout)
+    c = shell()
+    n = c.shape[0]
+    X, G = torch.randn(n, cin), torch.randn(n, cout)
+    Xb, Gb = X.to(torch.bfloat16), G.to(torch.bfloat16)
+    m = pcc.CoordMap(torch.from_numpy(c).to(DEV), 1)
+    nbr, order, gmask, _ = m.ordered_kernel_map(m, 3)
+    dw = torch.empty((27, cin, cout), dtype=torch.float32, device=DEV)
+    ne = L.pcc_conv_wgrad_scratch_elems(27, cin, cout)
+    scratch = torch.empty(ne, dtype=torch.float32, device=DEV)
+    xd, gd = Xb.to(DEV).contiguous(), Gb.to(DEV).contiguous()          # keep the device copies alive across the launch
+    check(L.pcc_conv_wgrad_bf16(ptr(xd), n, cin, ptr(gd), n, cout, ptr(nbr), ptr(order), ptr(gmask), 27, ptr(dw), ptr(scratch), ne,
+                                _lib.stream()))
+    nb = torch.from_numpy(oc.kernel_map(c, c, 3, 1)).long()
+    want = torch.zeros(27, cin, cout)
+    Xf, Gf = Xb.float(), Gb.float()
+    for k in range(27):
+        ok = nb[:, k] >= 0
+        want[k] = Xf[nb[ok, k]].t() @ Gf[ok]
+    got = dw.cpu()
+    assert torch.allclose(got, want, rtol=1e-4, atol=2e-5 * float(want.abs().max())), float((got - want).abs().max())
