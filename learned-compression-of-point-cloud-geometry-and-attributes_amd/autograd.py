@@ -128,25 +128,32 @@ class SparseConvFn(torch.autograd.Function):
         d_feats = d_kernel = d_bias = None
 
         if ctx.needs_input_grad[1]:
-            mfma = cin % 32 == 0 and cout % 32 == 0
+            # Thin shapes (q-map branches, input layer, narrow heads) are zero-padded to 32 channels and take the MFMA
+            # kernel too: the scalar kernel walks its rows serially and needs 60 ms for 2 -> 128 on 3.4 M rows where
+            # the padded MFMA launch takes 7 (16x the multiplications, all of them in the matrix pipe).
+            x_w, g_w = feats, dy
+            cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+            if cin_p != cin:
+                x_w = torch.cat([feats, torch.zeros((n_in, cin_p - cin), dtype=torch.float32, device=dev)], dim=1)
+            if cout_p != cout:
+                g_w = torch.cat([dy, torch.zeros((n_out, cout_p - cout), dtype=torch.float32, device=dev)], dim=1)
             if ksize == 1:
                 nbr = torch.arange(n_out, dtype=torch.int32, device=dev).unsqueeze(1).contiguous()
                 order = gmask = None
-            elif mfma:
-                nbr, order, gmask, _ = in_map.ordered_kernel_map(out_map, ksize, transposed)
             else:
-                nbr, _, _ = in_map.kernel_map(out_map, ksize, transposed)
-                order = gmask = None
-            dw = torch.empty((K, cin, cout), dtype=torch.float32, device=dev)
-            ne = L.pcc_conv_wgrad_scratch_elems(K, cin, cout)
+                nbr, order, gmask, _ = in_map.ordered_kernel_map(out_map, ksize, transposed)
+            dw = torch.empty((K, cin_p, cout_p), dtype=torch.float32, device=dev)
+            ne = L.pcc_conv_wgrad_scratch_elems(K, cin_p, cout_p)
             scratch = torch.empty(ne, dtype=torch.float32, device=dev)
             if BF16 and cin % 64 == 0 and cout % 64 == 0 and max(n_in * cin, n_out * cout) * 2 < 0xFFFFF000:
                 xb, gb = feats.to(torch.bfloat16), dy.to(torch.bfloat16)
                 check(L.pcc_conv_wgrad_bf16(ptr(xb), n_in, cin, ptr(gb), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
                                             ptr(scratch), ne, _lib.stream()))
             else:
-                check(L.pcc_conv_wgrad(ptr(feats), n_in, cin, ptr(dy), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
+                check(L.pcc_conv_wgrad(ptr(x_w), n_in, cin_p, ptr(g_w), n_out, cout_p, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
                                        ptr(scratch), ne, _lib.stream()))
+            if cin_p != cin or cout_p != cout:
+                dw = dw[:, :cin, :cout].contiguous()
             if out_channels is not None:
                 full = torch.zeros((K, cin, kshape[-1]), dtype=torch.float32, device=dev)
                 full[:, :, :out_channels] = dw
