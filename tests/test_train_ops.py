@@ -135,3 +135,29 @@ def test_conv_gradients_with_two_batch_items(pcc):
         assert close(out.detach().cpu(), ref.detach())
         assert close(x.grad.cpu(), Fo.grad), ("dX", cin, cout)
         assert close(layer.kernel.grad.cpu(), Wo.grad), ("dW", cin, cout)
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 64), (64, 1), (2, 2), (16, 16), (32, 3)])
+def test_scalar_weight_gradient_entry_point(pcc, cin, cout):
+    """pcc_conv_wgrad on shapes that are not multiples of 32 (the autograd function pads such shapes onto the
+    MFMA kernel; the C-ABI keeps a scalar kernel for direct callers)"""
+    from pcc_amd import _lib
+    from pcc_amd._lib import check, ptr
+    L = pcc.lib()
+    torch.manual_seed(cin + 31 * cout)
+    c = shell()
+    n = c.shape[0]
+    X, G = torch.randn(n, cin), torch.randn(n, cout)
+    m = pcc.CoordMap(torch.from_numpy(c).to(DEV), 1)
+    nbr, _, _ = m.kernel_map(m, 3)
+    dw = torch.empty((27, cin, cout), dtype=torch.float32, device=DEV)
+    ne = L.pcc_conv_wgrad_scratch_elems(27, cin, cout)
+    scratch = torch.empty(ne, dtype=torch.float32, device=DEV)
+    xd, gd = X.to(DEV), G.to(DEV)
+    check(L.pcc_conv_wgrad(ptr(xd), n, cin, ptr(gd), n, cout, ptr(nbr), None, None, 27, ptr(dw), ptr(scratch), ne, _lib.stream()))
+    nb = torch.from_numpy(oc.kernel_map(c, c, 3, 1)).long()
+    want = torch.zeros(27, cin, cout)
+    for k in range(27):
+        ok = nb[:, k] >= 0
+        want[k] = X[nb[ok, k]].t() @ G[ok]
+    assert close(dw.cpu(), want)
