@@ -21,11 +21,14 @@ def main():
     ap.add_argument("--block", type=int, default=128)
     args = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    rehearse = os.environ.get("PCC_BENCH_REHEARSE") == "1"      # one-GPU rehearsal of the N > 1 control flow: gloo, every rank on cuda:0
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
     import pcc_amd
     from pcc_amd import parallel as par, synthetic as syn
     from pcc_amd.loss import OURS_LOSS, Loss
@@ -81,7 +84,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el, float(npts)], dtype=torch.float64, device=dev)
+        t = torch.tensor([el, float(npts)], dtype=torch.float64, device="cpu" if rehearse else dev)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts)
         el, npts = float(tm[0]), float(ts[1])
