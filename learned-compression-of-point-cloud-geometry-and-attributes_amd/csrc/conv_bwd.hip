@@ -163,13 +163,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
 // bf16 operands (pcc_conv_wgrad_bf16; cin, cout multiples of 64): X and dY are bf16, products accumulate in fp32 on
 // v_mfma_f32_32x32x16_bf16.  The GEMM's K dimension is the ROWS, but the LDS images are [row][64 channels]
-// (128-B rows, what the 16-B-per-lane LDS-DMA produces), so a lane's 8 consecutive k-values of one channel are 8
-// two-byte reads 128 B apart — the operand transpose is paid in ds_read_u16 instructions instead of a second
-// staging pass.  The kernel is gather-bound like the bf16 forward, the extra LDS instructions hide under it.
+// (128-B rows, what the 16-B-per-lane LDS-DMA produces), so a lane's 8 consecutive k-values of one channel sit
+// 128 B apart.  gfx950's transposing LDS read does the operand transpose: ds_read_b64_tr_b16 takes, per 16-lane
+// group, a block of 4 rows x 16 columns (lane 4q+p addresses row q, columns 4p..4p+3) and hands lane i the 4 rows
+// of column i — two of them make one MFMA operand (8 two-byte reads plus packing without it: 2.2x slower).
+// Rows 128 B apart put rows q and q+2 on the same banks: the reads are 2-way conflicted, which hides under the
+// gathers the kernel is bound by.
 // A workgroup owns offset k, a block of up to 128 x 128 of W[k] = TM x TN tiles of 32 x 32 dealt round-robin to the
 // four waves (128 x 128: a wave holds one column of 4 tiles and reads its dY operand once), and every SPLIT-th
 // group of 32 rows (two MFMA k-steps).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -184,6 +190,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
     const int cbi = min(2, (a.cin - cin0) / 64), cbo = min(2, (a.cout - cout0) / 64);     // 64-channel chunks present
     const int TM = 2 * cbi, TN = 2 * cbo, NTILES = TM * TN;
+    // 64 x 64 blocks fill one image slot per operand: the other slot takes a SECOND row group per iteration (waves
+    // 0 / 2 stage the first group's X / dY, waves 1 / 3 the second's), doubling the MFMA work per barrier pair
+    const bool two_groups = cbi == 1 && cbo == 1;
 
     f32x16 acc[4];
 #pragma unroll
@@ -201,6 +210,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     // my tiles: t = wave, wave + 4, ...; tile t -> (m = t / TN, n = t % TN)
     int tm[4], tn[4];
     bool live[4];
+    // transposing read: my address inside a 4-row x 16-column block, and the block's first column within the tile
+    const int tr_off = (((lane & 15) >> 2) * 64) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int tt = wave_u + 4 * i;
@@ -216,18 +227,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
       while (todo) {
         const int bit = __ffsll(todo) - 1;
         todo &= todo - 1;
-        const int64_t g = gbase + (int64_t)bit * SPLIT;
+        int64_t g = gbase + (int64_t)bit * SPLIT;
+        bool second = false;
+        if (two_groups) {
+            int64_t g2 = -1;
+            if (todo) {
+                g2 = gbase + (int64_t)(__ffsll(todo) - 1) * SPLIT;
+                todo &= todo - 1;
+            }
+            second = g2 >= 0;
+            if (cw == 1) g = g2;                           // waves 1 and 3 stage the second group (chunk 0 of it)
+        }
+        const int chunk = two_groups ? 0 : cw;
         uint32_t vo[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t pos = g * 32 + 8 * i + rsub;
-            const bool ok = pos < a.n_out;
+            const bool ok = g >= 0 && pos < a.n_out;
             if (stage_x) {
                 const int idx = ok ? a.nbr[pos * a.K + k] : -1;
-                vo[i] = (idx >= 0 && cw < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 2) + (uint32_t)((cin0 + cw * 64) * 2 + slot * 16) : WG_OOB;
+                vo[i] = (idx >= 0 && chunk < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 2) + (uint32_t)((cin0 + chunk * 64) * 2 + slot * 16) : WG_OOB;
             } else {
                 const int64_t row = ok ? (a.order ? a.order[pos] : pos) : 0;
-                vo[i] = (ok && cw < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 2) + (uint32_t)((cout0 + cw * 64) * 2 + slot * 16) : WG_OOB;
+                vo[i] = (ok && chunk < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 2) + (uint32_t)((cout0 + chunk * 64) * 2 + slot * 16) : WG_OOB;
             }
         }
         unsigned short* dst = (stage_x ? As : Bs) + cw * 2048;
@@ -237,28 +259,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(dst + i * 512), 16, vo[i], 0, 0, 0);
         }
         __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {                       // rows 16 ks + 8 h + j
-            const int row0 = 16 * ks + 8 * h;
-            bf16x8 bop[4];
+        const int nks = (two_groups && second) ? 4 : 2;
+        for (int ks4 = 0; ks4 < nks; ++ks4) {                  // rows 16 ks + 8 h + j of group slot gs
+            const int ks = ks4 & 1, gs = ks4 >> 1;
+            const int row0 = 16 * ks + 8 * h;                   // first of my 8 rows (k-values) in this MFMA step
+            bf16x8 bop;
             int bn_loaded = -1;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (!live[i]) continue;
-                // operand of tile i: 8 rows of one channel, 128 B apart
-                const unsigned short* ap = As + (tm[i] >> 1) * 2048 + row0 * 64 + (tm[i] & 1) * 32 + r;
-                unsigned short av[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) av[j] = ap[j * 64];
+                if (!live[i]) continue;                         // wave-uniform: EXEC stays all ones for the transposing reads
+                const unsigned short* ap = As + ((tm[i] >> 1) + gs) * 2048 + row0 * 64 + (tm[i] & 1) * 32 + tr_off;
+                const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+                const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * 64));
+                const s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
                 if (tn[i] != bn_loaded) {                      // 128 x 128: all of the wave's tiles share n
-                    const unsigned short* bp = Bs + (tn[i] >> 1) * 2048 + row0 * 64 + (tn[i] & 1) * 32 + r;
-                    unsigned short bv[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) bv[j] = bp[j * 64];
-                    bop[0] = __builtin_bit_cast(bf16x8, bv);
+                    const unsigned short* bp = Bs + ((tn[i] >> 1) + gs) * 2048 + row0 * 64 + (tn[i] & 1) * 32 + tr_off;
+                    const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
+                    const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * 64));
+                    const s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                    bop = __builtin_bit_cast(bf16x8, b8);
                     bn_loaded = tn[i];
                 }
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), bop[0], acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), bop, acc[i], 0, 0, 0);
             }
         }
         __syncthreads();
