@@ -44,14 +44,19 @@ def _packed(w):
     return wp
 
 
+def _bf16_ok(rows, cin):
+    return BF16 and cin % 64 == 0 and rows * cin * 2 < 0xFFFFF000
+
+
 def _launch_conv(feats, w, bias, nbr, order, gmask, n_out):
+    """feats: fp32, or an already cast bf16 copy (bf16 mode: one cast per tensor, shared by its consumers)"""
     L = _lib.lib()
     K, cin, cout = w.shape
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-    if BF16 and cin % 64 == 0 and feats.shape[0] * cin * 2 < 0xFFFFF000:
+    if feats.dtype == torch.bfloat16 or _bf16_ok(feats.shape[0], cin):
         wp = torch.empty(L.pcc_conv_packed_elems_bf16(K, cin, cout), dtype=torch.bfloat16, device=feats.device)
         check(L.pcc_conv_pack_weights_bf16(ptr(w), K, cin, cout, ptr(wp), _lib.stream()))
-        x = feats.to(torch.bfloat16)
+        x = feats if feats.dtype == torch.bfloat16 else feats.to(torch.bfloat16)
         check(L.pcc_conv_fwd_bf16(ptr(x), feats.shape[0], cin, ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K, ptr(out),
                                   n_out, cout, 0, None, None, _lib.stream()))
         return out
@@ -111,6 +116,8 @@ class SparseConvFn(torch.autograd.Function):
             b = None if b is None else b[:out_channels].contiguous()
         w = w.contiguous()
         nbr, order, gmask = _forward_map(in_map, out_map, ksize, transposed, feats.shape[1])
+        if _bf16_ok(feats.shape[0], feats.shape[1]):
+            feats = feats.to(torch.bfloat16)          # the one cast of this tensor: forward now, weight gradient later
         out = _launch_conv(feats, w, b, nbr, order, gmask, out_map.n)
         ctx.save_for_backward(feats, w)
         ctx.meta = (in_map, out_map, ksize, transposed, out_channels, tuple(kernel.shape), bias is not None)
@@ -131,12 +138,15 @@ class SparseConvFn(torch.autograd.Function):
             # Thin shapes (q-map branches, input layer, narrow heads) are zero-padded to 32 channels and take the MFMA
             # kernel too: the scalar kernel walks its rows serially and needs 60 ms for 2 -> 128 on 3.4 M rows where
             # the padded MFMA launch takes 7 (16x the multiplications, all of them in the matrix pipe).
-            x_w, g_w = feats, dy
-            cin_p, cout_p = (cin + 31) // 32 * 32, (cout + 31) // 32 * 32
+            bf = feats.dtype == torch.bfloat16             # forward ran in bf16: the saved input is the bf16 copy
+            unit = 64 if bf else 32
+            cin_p, cout_p = (cin + unit - 1) // unit * unit, (cout + unit - 1) // unit * unit
+            x_w = feats
+            g_w = dy.to(torch.bfloat16) if bf else dy
             if cin_p != cin:
-                x_w = torch.cat([feats, torch.zeros((n_in, cin_p - cin), dtype=torch.float32, device=dev)], dim=1)
+                x_w = torch.cat([x_w, torch.zeros((n_in, cin_p - cin), dtype=x_w.dtype, device=dev)], dim=1)
             if cout_p != cout:
-                g_w = torch.cat([dy, torch.zeros((n_out, cout_p - cout), dtype=torch.float32, device=dev)], dim=1)
+                g_w = torch.cat([g_w, torch.zeros((n_out, cout_p - cout), dtype=g_w.dtype, device=dev)], dim=1)
             if ksize == 1:
                 nbr = torch.arange(n_out, dtype=torch.int32, device=dev).unsqueeze(1).contiguous()
                 order = gmask = None
@@ -145,9 +155,8 @@ class SparseConvFn(torch.autograd.Function):
             dw = torch.empty((K, cin_p, cout_p), dtype=torch.float32, device=dev)
             ne = L.pcc_conv_wgrad_scratch_elems(K, cin_p, cout_p)
             scratch = torch.empty(ne, dtype=torch.float32, device=dev)
-            if BF16 and cin % 64 == 0 and cout % 64 == 0 and max(n_in * cin, n_out * cout) * 2 < 0xFFFFF000:
-                xb, gb = feats.to(torch.bfloat16), dy.to(torch.bfloat16)
-                check(L.pcc_conv_wgrad_bf16(ptr(xb), n_in, cin, ptr(gb), n_out, cout, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
+            if bf:
+                check(L.pcc_conv_wgrad_bf16(ptr(x_w), n_in, cin_p, ptr(g_w), n_out, cout_p, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
                                             ptr(scratch), ne, _lib.stream()))
             else:
                 check(L.pcc_conv_wgrad(ptr(x_w), n_in, cin_p, ptr(g_w), n_out, cout_p, ptr(nbr), ptr(order), ptr(gmask), K, ptr(dw),
@@ -170,7 +179,7 @@ class SparseConvFn(torch.autograd.Function):
 
         if ctx.needs_input_grad[0]:
             wt = w.transpose(1, 2)                                  # [K, cout, cin]
-            g = dy
+            g = g_w if (ctx.needs_input_grad[1] and feats.dtype == torch.bfloat16 and cout % 64 == 0 and _bf16_ok(n_out, cout)) else dy
             if cout % 32 and cout not in _THIN_CIN:                 # the thin forward kernel takes 1, 2, 4, 8 or 16 input channels
                 pad = next(c for c in _THIN_CIN if c >= cout) - cout
                 g = torch.cat([dy, torch.zeros((n_out, pad), dtype=torch.float32, device=dev)], dim=1).contiguous()
