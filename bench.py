@@ -43,6 +43,9 @@ def parse():
                     help="N > 1 sharding: one frame per rank (weak scaling, the default) or the cubes of ONE frame "
                          "spread over the ranks (strong scaling; different numbers than whole-frame coding, SURVEY.md 8e)")
     ap.add_argument("--block", type=int, default=512, help="cube edge of --partition blocks")
+    ap.add_argument("--weights", default=None,
+                    help="state_dict to load instead of the seeded initialisation (e.g. from tools/train.py); the headline "
+                         "configuration is the seeded one")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -105,6 +108,8 @@ def main():
     from pcc_amd import sparse as sp
     syn = pcc_amd.synthetic
     model = syn.make_model(0, dev)
+    if args.weights:
+        model.load_state_dict(torch.load(args.weights, map_location=dev))
     model.update()
 
     cfg = {"config1": syn.CONFIG1, "config2": syn.CONFIG2, "mid": dict(grid=256, radius=100.0, half_width=0.5)}[args.workload]
@@ -307,7 +312,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {cfg['grid']}^3 voxel sphere shell r={cfg['radius']}, N={N} points/frame, "
-                               "q=(0.5,0.5), configs/Ours.yaml, seeded random weights, in-memory compress+decompress, "
+                               f"q=(0.5,0.5), configs/Ours.yaml, {'weights from ' + os.path.basename(args.weights) if args.weights else 'seeded random weights'}, in-memory compress+decompress, "
                                + (f"ONE frame per step cut into {args.block}^3 cubes spread over the ranks by point count"
                                   if blocks_mode else "one frame per rank per step"),
                    "points_per_frame": N,

@@ -169,9 +169,9 @@ class _EntropyModelBase(nn.Module):
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
         # table buffers change size between a fresh module and an updated checkpoint
-        for name in ("_offset", "_quantized_cdf", "_cdf_length"):
+        for name in ("_offset", "_quantized_cdf", "_cdf_length", "scale_table"):
             key = prefix + name
-            if key in state_dict:
+            if key in state_dict and hasattr(self, name):
                 setattr(self, name, state_dict[key].clone().to(getattr(self, name).device))
         self._host_tables = None
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)

@@ -297,3 +297,22 @@ def test_two_worker_threads_produce_identical_frames(pcc):
     [t.join() for t in ths]
     assert not errs, errs
     assert [got[i] for i in range(12)] == [want[i % 3] for i in range(12)]
+
+
+@pytest.mark.gpu
+def test_updated_checkpoint_round_trips_through_state_dict(pcc, tmp_path):
+    """evaluate.py:80-84: weights saved after update() (tables and scale table filled) load into a fresh model
+    with strict=True and code the same bytes"""
+    syn = pcc.synthetic
+    a = syn.make_model(0, "cuda:0")
+    a.update()
+    path = str(tmp_path / "weights.pt")
+    torch.save(a.state_dict(), path)
+    b = pcc.ColorModel(syn.OURS_CONFIG).to("cuda:0").eval()
+    b.load_state_dict(torch.load(path, map_location="cuda:0"), strict=True)
+    pts, qc, qf = _inputs(pcc, dict(grid=32, radius=15.0, half_width=0.875))
+    sa = _compress(pcc, a, pts, qc, qf)
+    sb = _compress(pcc, b, pts, qc, qf)                   # no update() needed: the tables came with the checkpoint
+    assert sa[0] == sb[0] and sa[1] == sb[1] and sa[2] == sb[2]
+    b.update()
+    assert _compress(pcc, b, pts, qc, qf)[0] == sa[0]
