@@ -4,7 +4,7 @@ redandblack / loot / longdress / soldier x the 4 (q_g, q_a) pairs of plot.py:31-
 file-mode compress / decompress + GPU metrics; Bjontegaard deltas between the frames' curves.
 Seeded random weights: the rates and PSNRs exercise the pipeline, they are not codec quality.
 
-usage: rd_sweep.py [out.json]"""
+usage: rd_sweep.py [out.json] [weights.pt]"""
 import json, os, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,7 +17,10 @@ from pcc_amd.metrics import Bjontegaard_Delta, Bjontegaard_Model
 dev = "cuda:0"
 FRAMES = {"redandblack~": 247.0, "loot~": 255.0, "longdress~": 261.5, "soldier~": 294.5}   # shell radii -> ~0.76 / 0.81 / 0.86 / 1.09 M
 QS = [(0.05, 0.1), (0.1, 0.2), (0.2, 0.4), (0.4, 0.8)]
-model = syn.make_model(seed=0, device=dev); model.update()
+model = syn.make_model(seed=0, device=dev)
+if len(sys.argv) > 2:
+    model.load_state_dict(torch.load(sys.argv[2], map_location=dev))
+model.update()
 rows = []
 with tempfile.TemporaryDirectory() as td:
     for name, radius in FRAMES.items():
@@ -41,7 +44,9 @@ for nm in names[1:]:
         bd[nm] = {"bd_psnr_y_vs_" + names[0]: float(Bjontegaard_Delta().compute_BD_PSNR(m1, m2))}
     except Exception as e:      # degenerate curves (seeded weights) must not lose the table
         bd[nm] = {"error": repr(e)}
-out = {"rows": rows, "bjontegaard": bd, "note": "seeded random weights; synthetic shells sized like the 8iVFB frames"}
+out = {"rows": rows, "bjontegaard": bd,
+       "note": ("weights from " + os.path.basename(sys.argv[2]) if len(sys.argv) > 2 else "seeded random weights") +
+               "; synthetic shells sized like the 8iVFB frames"}
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "rd_sweep.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
