@@ -677,17 +677,29 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
         float acc[CPT];
 #pragma unroll
         for (int j = 0; j < CPT; ++j) acc[j] = 0.0f;
-        for (int k = 0; k < K; ++k) {
-            const int idx = a.nbr ? a.nbr[row * K + k] : (int)row;
-            if (idx < 0) continue;
-            float in[CIN];
+        // Offsets in blocks of 9 (one z-slice): the 9 indices are loaded first, then the 9 gathers — independent
+        // loads in flight instead of 27 dependent index -> value round trips per row.  The FMAs keep their order
+        // (k ascending) and absent neighbours are still skipped, so results are unchanged bit for bit.
+        for (int k0 = 0; k0 < K; k0 += 9) {
+            int idx[9];
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci) in[ci] = a.fin[(int64_t)idx * CIN + ci];
-            const float* wk = smem + (k * CIN) * cout + co;
+            for (int u = 0; u < 9; ++u) idx[u] = (k0 + u < K) ? (a.nbr ? a.nbr[row * K + k0 + u] : (int)row) : -1;
+            float in[9][CIN];
 #pragma unroll
-            for (int ci = 0; ci < CIN; ++ci)
+            for (int u = 0; u < 9; ++u) {
+                const int64_t src = idx[u] >= 0 ? idx[u] : 0;          // row 0 always exists; its values are not used
 #pragma unroll
-                for (int j = 0; j < CPT; ++j) acc[j] = fmaf(in[ci], wk[ci * cout + j], acc[j]);
+                for (int ci = 0; ci < CIN; ++ci) in[u][ci] = a.fin[src * CIN + ci];
+            }
+#pragma unroll
+            for (int u = 0; u < 9; ++u) {
+                if (idx[u] < 0) continue;
+                const float* wk = smem + ((k0 + u) * CIN) * cout + co;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                    for (int j = 0; j < CPT; ++j) acc[j] = fmaf(in[u][ci], wk[ci * cout + j], acc[j]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < CPT; ++j) {
