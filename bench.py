@@ -210,8 +210,8 @@ def main():
             return (n_out + 31) // 32
         key = gmask.data_ptr()
         if key not in pop_cache:
-            g = gmask.to(torch.int64) & 0xFFFFFFFF
-            pop_cache[key] = int(sum(((g >> i) & 1).sum() for i in range(27)).item())
+            # counted on the host: 27 tiny device reductions per map would fill the kernel trace
+            pop_cache[key] = int(np.unpackbits(gmask.cpu().numpy().view(np.uint8)).sum())
         return pop_cache[key]
 
     launches = []

@@ -740,6 +740,57 @@ __global__ __launch_bounds__(256) void gather_sum_kernel(const float* __restrict
     }
 }
 
+// K = 27 form of the same sum with the memory operations batched.  A block owns 256 consecutive output rows: their
+// 256 x 27 neighbour indices (27,648 contiguous bytes) are staged through LDS with 16-byte coalesced loads (a lane
+// reading its own 108-byte row from global touches a new line almost every step), then each thread walks its row in
+// z-slices of 9 offsets — 9 independent score gathers in flight instead of 27 index -> score round trips.  Absent
+// neighbours are still skipped and k still ascends, so the sum is the one gather_sum_kernel computes, bit for bit.
+template <int COUT>
+__global__ __launch_bounds__(256) void gather_sum27_kernel(const float* __restrict__ scores, int ld,
+                                                           const int32_t* __restrict__ nbr, const float* __restrict__ bias,
+                                                           float* __restrict__ out, int64_t n_out, int act) {
+    __shared__ __attribute__((aligned(16))) int32_t idx_s[256 * 27];
+    const int64_t row0 = (int64_t)blockIdx.x * 256;
+    const int64_t rows = (n_out - row0 < 256) ? (n_out - row0) : 256;
+    const int64_t words = rows * 27;
+    const int32_t* src = nbr + row0 * 27;                 // 27,648 B per block: 16-byte aligned
+    for (int64_t w = 4 * (int64_t)threadIdx.x; w < words; w += 1024) {
+        if (w + 4 <= words) {
+            *reinterpret_cast<int4*>(idx_s + w) = *reinterpret_cast<const int4*>(src + w);
+        } else {
+            for (int64_t u = w; u < words; ++u) idx_s[u] = src[u];
+        }
+    }
+    __syncthreads();
+    if ((int64_t)threadIdx.x >= rows) return;
+    const int32_t* mine = idx_s + threadIdx.x * 27;       // stride 27 words: conflict-free
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int k0 = 0; k0 < 27; k0 += 9) {
+        int idx[9];
+        float v[9][COUT];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) idx[u] = mine[k0 + u];
+#pragma unroll
+        for (int u = 0; u < 9; ++u) {
+            const float* sp = scores + (int64_t)(idx[u] >= 0 ? idx[u] : 0) * ld + (k0 + u) * COUT;   // row 0 exists; unused
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) v[u][c] = sp[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 9; ++u)
+            if (idx[u] >= 0) {
+#pragma unroll
+                for (int c = 0; c < COUT; ++c) acc[c] += v[u][c];
+            }
+    }
+    float* o = out + (row0 + threadIdx.x) * COUT;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) o[c] = apply_act(acc[c] + (bias ? bias[c] : 0.0f), act);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
 static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
@@ -897,8 +948,17 @@ int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int3
     PCC_REQUIRE(nbr != nullptr, "pcc_gather_sum_fwd: neighbour table required");
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_gather_sum_fwd: bad activation %d", act);
     if (n_out <= 0) return PCC_OK;
-    hipLaunchKernelGGL(gather_sum_kernel, dim3(blocks_for(n_out * cout, 256, 1 << 20)), dim3(256), 0, as_stream(stream),
-                       scores, ld, nbr, K, cout, bias, out, n_out, act);
+    const unsigned nb27 = blocks_for(n_out, 256);
+#define PCC_GS27(C)                                                                                                    \
+    hipLaunchKernelGGL(gather_sum27_kernel<C>, dim3(nb27), dim3(256), 0, as_stream(stream), scores, ld, nbr, bias, out, n_out, act)
+    if (K == 27 && cout == 1) PCC_GS27(1);
+    else if (K == 27 && cout == 2) PCC_GS27(2);
+    else if (K == 27 && cout == 3) PCC_GS27(3);
+    else if (K == 27 && cout == 4) PCC_GS27(4);
+    else
+#undef PCC_GS27
+        hipLaunchKernelGGL(gather_sum_kernel, dim3(blocks_for(n_out * cout, 256, 1 << 20)), dim3(256), 0, as_stream(stream),
+                           scores, ld, nbr, K, cout, bias, out, n_out, act);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -308,6 +308,29 @@ def test_conv_on_operands_beyond_4gib(pcc):
     del F, out
 
 
+@pytest.mark.parametrize("cout,K,n_out", [(1, 27, 1000), (3, 27, 777), (2, 27, 256), (4, 27, 513), (1, 8, 300), (1, 27, 1)])
+def test_gather_sum_matches_sequential_sum_bitwise(pcc, cout, K, n_out):
+    """second half of the narrow-head path (occupancy logit, colour head): out[j, c] = bias[c] + sum over present
+    offsets k, ascending, of scores[nbr[j, k], k * cout + c] — fp32 adds in a fixed order, so exact"""
+    from pcc_amd._lib import lib, check, ptr, stream
+    rng = np.random.default_rng(cout * 100 + K)
+    n_in = 900
+    nbr = rng.integers(0, n_in, size=(n_out, K)).astype(np.int32)
+    nbr[rng.random((n_out, K)) < 0.45] = -1
+    nbr[0, :] = -1                                            # a row without neighbours
+    scores = rng.standard_normal((n_in, K * cout)).astype(np.float32)
+    bias = rng.standard_normal(cout).astype(np.float32)
+    want = np.zeros((n_out, cout), np.float32)
+    for k in range(K):
+        got_k = scores[np.maximum(nbr[:, k], 0), k * cout:(k + 1) * cout]
+        want = np.where((nbr[:, k] >= 0)[:, None], want + got_k, want).astype(np.float32)
+    want = np.maximum(want + bias[None, :], 0).astype(np.float32)           # act 1 = ReLU
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=DEV)
+    d_scores, d_nbr, d_bias = dev(scores), dev(nbr), dev(bias)
+    check(lib().pcc_gather_sum_fwd(ptr(d_scores), K * cout, ptr(d_nbr), K, cout, ptr(d_bias), ptr(out), n_out, 1, stream()))
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 def test_gather_scatter_compact(pcc):
     from pcc_amd import sparse as sp
     rng = np.random.default_rng(2)
