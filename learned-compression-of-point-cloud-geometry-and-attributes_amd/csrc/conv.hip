@@ -873,7 +873,9 @@ static int launch_thin(const ConvArgs& a, hipStream_t st) {
     PCC_REQUIRE(lds <= 64 * 1024, "conv(thin): weights %zu B exceed LDS budget (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
     // channels per thread: the largest of 8, 4, 2, 1 dividing cout
     const int cpt = (a.cout % 8 == 0) ? 8 : (a.cout % 4 == 0) ? 4 : (a.cout % 2 == 0) ? 2 : 1;
-    const unsigned nb = blocks_for(a.n_out * (a.cout / cpt), 256, 1 << 20);
+    // every block stages the whole weight tensor into LDS first (27.6 KB for 2 -> 128): a few resident blocks per CU
+    // that stride over the rows, not one block per 256 outputs
+    const unsigned nb = blocks_for(a.n_out * (a.cout / cpt), 256, lds >= 4096 ? 2048u : (1u << 20));
     if (cpt == 8) hipLaunchKernelGGL((conv_thin_kernel<CIN, 8>), dim3(nb), dim3(256), lds, st, a);
     else if (cpt == 4) hipLaunchKernelGGL((conv_thin_kernel<CIN, 4>), dim3(nb), dim3(256), lds, st, a);
     else if (cpt == 2) hipLaunchKernelGGL((conv_thin_kernel<CIN, 2>), dim3(nb), dim3(256), lds, st, a);
