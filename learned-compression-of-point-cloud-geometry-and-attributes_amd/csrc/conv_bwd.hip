@@ -92,38 +92,61 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
     // my groups are s, s + SPLIT, ...; 64 of their masks are inspected per load (one per lane) and only the
     // groups that hold offset k are visited: a dependent scalar load per skipped group would cost ~1 us each
-    for (int64_t gbase = s; gbase < ng; gbase += 64 * SPLIT) {
-      const int64_t gmine = gbase + (int64_t)lane * SPLIT;
-      const uint32_t gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
-      unsigned long long live = __ballot((gml >> k) & 1u);
-      while (live) {
+    int64_t gb = (int64_t)s - 64 * (int64_t)SPLIT;
+    unsigned long long live = 0ull;
+    auto pop = [&]() -> int64_t {                          // next of my groups that holds offset k, or -1
+        while (!live) {
+            gb += 64 * (int64_t)SPLIT;
+            if (gb >= ng) return -1;
+            const int64_t gmine = gb + (int64_t)lane * SPLIT;
+            const uint32_t gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
+            live = __ballot((gml >> k) & 1u);
+        }
         const int bit = __ffsll(live) - 1;
         live &= live - 1;
-        int64_t g = gbase + (int64_t)bit * SPLIT;
-        if (rowsplit) {                                   // second group of the iteration (or none: zero images)
-            int64_t g2 = -1;
-            if (live) {
-                g2 = gbase + (int64_t)(__ffsll(live) - 1) * SPLIT;
-                live &= live - 1;
-            }
+        return gb + (int64_t)bit * SPLIT;
+    };
+    auto take = [&](bool& any) -> int64_t {                // this wave's group of the next iteration
+        int64_t g = pop();
+        any = g >= 0;
+        if (rowsplit) {                                    // second group of the iteration (or none: zero images)
+            const int64_t g2 = any ? pop() : -1;
             if (wave_u >= 2) g = g2;
         }
+        return g;
+    };
+    // The neighbour indices and dY rows of a group are fetched one iteration ahead, beside the previous group's
+    // gathers: an iteration then waits for one memory round trip (the gathers), not for two in sequence.
+    int idx[4];
+    int64_t row[4];
+    bool okr[4];
+    auto load_rows = [&](int64_t g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t pos = g * 32 + 8 * i + rsub;
+            okr[i] = g >= 0 && pos < a.n_out;
+            idx[i] = okr[i] ? a.nbr[pos * a.K + k] : -1;
+            row[i] = okr[i] ? (a.order ? a.order[pos] : pos) : 0;
+        }
+    };
+    bool any;
+    int64_t g = take(any);
+    load_rows(g);
+    while (any) {
         // wave w stages one chunk of both operands: 4 instructions x 8 rows each
         uint32_t voa[4], vob[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int64_t pos = g * 32 + 8 * i + rsub;
-            const bool ok = g >= 0 && pos < a.n_out;
-            const int idx = ok ? a.nbr[pos * a.K + k] : -1;
-            const int64_t row = ok ? (a.order ? a.order[pos] : pos) : 0;
-            voa[i] = (idx >= 0 && cw < cbi) ? (uint32_t)idx * (uint32_t)(a.cin * 4) + (uint32_t)((cin0 + cw * 32) * 4 + slot * 16) : WG_OOB;
-            vob[i] = (ok && cw < cbo) ? (uint32_t)row * (uint32_t)(a.cout * 4) + (uint32_t)((cout0 + cw * 32) * 4 + slot * 16) : WG_OOB;
+            voa[i] = (idx[i] >= 0 && cw < cbi) ? (uint32_t)idx[i] * (uint32_t)(a.cin * 4) + (uint32_t)((cin0 + cw * 32) * 4 + slot * 16) : WG_OOB;
+            vob[i] = (okr[i] && cw < cbo) ? (uint32_t)row[i] * (uint32_t)(a.cout * 4) + (uint32_t)((cout0 + cw * 32) * 4 + slot * 16) : WG_OOB;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(As + wave_u * 1024 + i * 256), 16, voa[i], 0, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Bs + wave_u * 1024 + i * 256), 16, vob[i], 0, 0, 0);
         }
+        g = take(any);
+        load_rows(g);
         __syncthreads();
         const float* Ab = As + slotA * 1024 + h * 32 + r;
         const float* Bb = Bs + slotB * 1024 + h * 32 + r;
@@ -139,7 +162,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
                 for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
         }
         __syncthreads();
-      }
     }
 
     // D[row = (reg & 3) + 8 (reg >> 2) + 4 h][col = r] of each 32 x 32 tile: row = input channel, col = output channel
