@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training-step throughput (BASELINE config 5 shape: cubes cut from a 10-bit frame, batch of cubes per
-step, Adam, data-parallel gradient averaging over RCCL).  fp32 (the MFMA kernels are fp32; the bf16
-variant named by config 5 is not built).  Synthetic data: the config-2 shell cut into 128^3 cubes
+step, Adam, data-parallel gradient averaging over RCCL).  fp32 by default; PCC_TRAIN_BF16=1 runs the wide
+convolutions (forward, backward-data, weight gradient) on bf16 operands with fp32 accumulation.  Synthetic data: the config-2 shell cut into 128^3 cubes
 (data/datasets/full_128), colours as in bench.py; seeded weights.
 
   python tools/train_bench.py [--batch 8] [--steps 5] [--warmup 2] [--block 128]
