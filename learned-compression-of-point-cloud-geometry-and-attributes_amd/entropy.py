@@ -104,6 +104,16 @@ def _to_host(t, key):
     return buf.numpy().reshape(t.shape)
 
 
+def _to_host_async(t, key):
+    """Like _to_host without the wait: -> (numpy view, event); the view is valid after ``event.synchronize()``."""
+    t = t.contiguous()
+    buf = _pinned(key, t.numel(), t.dtype)
+    buf.copy_(t.reshape(-1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+    return buf.numpy().reshape(t.shape), ev
+
+
 def _to_device(arr, device, key):
     """numpy array -> device tensor through a pinned staging buffer."""
     src = torch.from_numpy(np.ascontiguousarray(arr))
@@ -303,10 +313,29 @@ class EntropyBottleneck(_EntropyModelBase):
         sym, zhat = self.quantize_features(z_feats)
         if perm is not None:
             sym = sym.index_select(1, perm.long())
+        finish, _ = self._encode_begin(sym)
+        return finish(), zhat
+
+    def _encode_begin(self, sym):
         cdf, cdf_len, off = self.tables()
         c, n = sym.shape
-        idx = np.repeat(np.arange(c, dtype=np.int32), n)
-        return [_rans_encode(_to_host(sym, "eb_sym"), idx, cdf, cdf_len, off)], zhat
+        host, ev = _to_host_async(sym, "eb_sym")
+
+        def finish():
+            ev.synchronize()
+            return [_rans_encode(host, np.repeat(np.arange(c, dtype=np.int32), n), cdf, cdf_len, off)]
+
+        return finish, ev
+
+    def compress_features_begin(self, z_feats, perm=None):
+        """Two-phase form of compress_features: quantisation and the copy to the host are enqueued now; the returned
+        function waits for the copy and runs the (serial, host) range coder — in between the caller can enqueue the
+        GPU work that only needs z_hat (h_s, the preparation of the y symbols).  -> (finish() -> [bytes], z_hat)"""
+        sym, zhat = self.quantize_features(z_feats)
+        if perm is not None:
+            sym = sym.index_select(1, perm.long())
+        finish, _ = self._encode_begin(sym)
+        return finish, zhat
 
     def compress(self, x):
         strings, _ = self.compress_features(x[0].t().contiguous())
@@ -387,9 +416,25 @@ class GaussianConditional(_EntropyModelBase):
         if perm is not None:
             p = perm.long()
             sym, idx = sym.index_select(1, p), idx.index_select(1, p)
+        return self._encode_begin(sym, idx)()
+
+    def _encode_begin(self, sym, idx):
         cdf, cdf_len, off = self.tables()
-        both = _to_host(torch.stack([sym, idx]), "gc_sym_idx")
-        return [_rans_encode(both[0], both[1], cdf, cdf_len, off)]
+        both, ev = _to_host_async(torch.stack([sym, idx]), "gc_sym_idx")
+
+        def finish():
+            ev.synchronize()
+            return [_rans_encode(both[0], both[1], cdf, cdf_len, off)]
+
+        return finish
+
+    def compress_features_begin(self, y_feats, params, perm=None):
+        """Two-phase form of compress_features (see EntropyBottleneck.compress_features_begin) -> finish() -> [bytes]"""
+        sym, idx = self.encode_prep(y_feats, params)
+        if perm is not None:
+            p = perm.long()
+            sym, idx = sym.index_select(1, p), idx.index_select(1, p)
+        return self._encode_begin(sym, idx)
 
     def decompress_features(self, strings, params, c):
         """params rows must be in the bitstream's row order.  -> y_hat [N, C]."""

@@ -98,10 +98,14 @@ class MeanScaleHyperprior_Map(nn.Module):
         perm_y = y.map.sort_permutation()
         perm_z = z.map.sort_permutation()
         shape = [z.map.n]
-        z_strings, z_hat_f = self.entropy_bottleneck.compress_features(z.F, perm=perm_z)
+        # the host range coder of z runs while the GPU computes h_s and prepares the y symbols: everything the
+        # GPU still has to do is enqueued before the first host wait
+        finish_z, z_hat_f = self.entropy_bottleneck.compress_features_begin(z.F, perm=perm_z)
         z_hat = SparseTensor(z_hat_f, coordinate_map=z.map)
         params = self._params_at(z_hat, y.map)
-        y_strings = self.gaussian_conditional.compress_features(y.F, params, perm=perm_y)
+        finish_y = self.gaussian_conditional.compress_features_begin(y.F, params, perm=perm_y)
+        z_strings = finish_z()
+        y_strings = finish_y()
         points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
         return points, [y_strings, z_strings], shape
 
