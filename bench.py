@@ -23,6 +23,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# the pool's host driver shares device memory between processes (RCCL) through dmabuf only
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np
 import torch
 

@@ -9,6 +9,8 @@ cubes cut from synthetic shells (no dataset in this environment) or from PLY fil
 import argparse, glob, json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the pool's host driver shares device memory between processes (RCCL) through dmabuf only
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np, torch
 
 

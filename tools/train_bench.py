@@ -10,6 +10,8 @@ convolutions (forward, backward-data, weight gradient) on bf16 operands with fp3
 import argparse, json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the pool's host driver shares device memory between processes (RCCL) through dmabuf only
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import numpy as np, torch
 
 
