@@ -132,3 +132,32 @@ def test_sparse_collate(pcc):
     assert torch.equal(C[a.shape[0]:, 1:].float(), torch.from_numpy(b[:, :3]))
     with pytest.raises(ValueError):
         sparse_collate([torch.zeros(3, 3)], [torch.zeros(2, 3)])
+
+
+def test_prefetcher_keeps_order_and_surfaces_errors(pcc):
+    """batch pipeline of the training tools: same sequence as a plain loop, exceptions reach the consumer"""
+    import random
+    import torch
+    from pcc_amd.utils import Prefetcher
+    rng = random.Random(7)
+    want = [random.Random(7).sample(range(100), 3)]
+    r2 = random.Random(7)
+    want = [r2.sample(range(100), 3) for _ in range(6)]
+    feed = Prefetcher(lambda: (torch.tensor(rng.sample(range(100), 3)), "tag"), depth=2, pin=False)
+    got = [next(feed) for _ in range(6)]
+    feed.close()
+    assert [g[0].tolist() for g in got] == want and all(g[1] == "tag" for g in got)
+
+    calls = {"n": 0}
+
+    def bad():
+        calls["n"] += 1
+        if calls["n"] == 3:
+            raise ValueError("broken sample")
+        return calls["n"]
+
+    feed = Prefetcher(bad, depth=1, pin=False)
+    assert next(feed) == 1 and next(feed) == 2
+    with pytest.raises(ValueError):
+        next(feed)
+    feed.close()

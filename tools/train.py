@@ -61,14 +61,19 @@ def main():
     qgen = Q_Map({"mode": "exponential", "lambda_A_max": 12800, "lambda_A_min": 100, "lambda_G_max": 1600, "lambda_G_min": 25})
     loss_fn = Loss(OURS_LOSS)
     t0 = time.time()
-    for step in range(1, args.steps + 1):
+    def batch():
         pick = rng.sample(range(len(cubes)), min(args.batch, len(cubes)))
         cs, fs = [], []
         for i in pick:
             p = cubes[i]
             cs.append(torch.from_numpy(p[:, :3] - np.floor(p[:, :3].min(axis=0) / args.block) * args.block))
             fs.append(torch.from_numpy(p[:, 3:6]))
-        C, F = sparse_collate(cs, fs, device=dev)
+        return sparse_collate(cs, fs)
+
+    feed = pcc_amd.utils.Prefetcher(batch, depth=2)       # cut on a background thread, like the reference's DataLoader workers
+    for step in range(1, args.steps + 1):
+        C, F = next(feed)
+        C, F = C.to(dev, non_blocking=True), F.to(dev, non_blocking=True)
         inp = pcc_amd.SparseTensor(coordinates=C, features=F, device=dev)
         Q, Lam = qgen(inp)
         opt.zero_grad(set_to_none=True)
@@ -85,6 +90,7 @@ def main():
             print(f"step {step:5d}  loss {float(total.detach()):9.3f}  " +
                   "  ".join(f"{k} {float(v.detach()):.3f}" for k, v in parts.items()) +
                   f"  aux {float(aux.detach()):.1f}  {time.time() - t0:.0f} s", flush=True)
+    feed.close()
     if rank == 0:
         model.eval()
         model.update()

@@ -57,10 +57,14 @@ def main():
             xyz = p[:, :3] - np.floor(p[:, :3].min(axis=0) / args.block) * args.block       # cube-local coordinates
             cs.append(np.concatenate([np.full((p.shape[0], 1), b, np.float32), xyz], axis=1))
             fs.append(p[:, 3:])
-        return torch.from_numpy(np.concatenate(cs)).to(dev), torch.from_numpy(np.concatenate(fs)).to(dev)
+        return torch.from_numpy(np.concatenate(cs)), torch.from_numpy(np.concatenate(fs))
+
+    # batches are cut on a background thread while the GPU works (the reference's DataLoader workers, train.py:171-187)
+    feed = pcc_amd.utils.Prefetcher(batch, depth=2)
 
     def step():
-        c, f = batch()
+        c, f = next(feed)
+        c, f = c.to(dev, non_blocking=True), f.to(dev, non_blocking=True)
         inp = pcc_amd.SparseTensor(coordinates=c, features=f, device=dev)
         Q, Lam = qgen(inp)
         opt.zero_grad(set_to_none=True)
@@ -94,6 +98,7 @@ def main():
         print(json.dumps({"metric": "training points/sec", "value": npts / el, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                           "ms_per_step": el / args.steps * 1e3, "batch_cubes_per_gpu": args.batch, "block": args.block,
                           "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic"}))
+    feed.close()
     if world > 1:
         dist.destroy_process_group()
 
