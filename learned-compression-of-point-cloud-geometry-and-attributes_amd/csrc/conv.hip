@@ -951,12 +951,13 @@ int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int3
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_gather_sum_fwd: bad activation %d", act);
     if (n_out <= 0) return PCC_OK;
     const unsigned nb27 = blocks_for(n_out, 256);
+    const bool al16 = (reinterpret_cast<uintptr_t>(nbr) & 15) == 0;      // the K = 27 kernel stages indices with 16-byte loads
 #define PCC_GS27(C)                                                                                                    \
     hipLaunchKernelGGL(gather_sum27_kernel<C>, dim3(nb27), dim3(256), 0, as_stream(stream), scores, ld, nbr, bias, out, n_out, act)
-    if (K == 27 && cout == 1) PCC_GS27(1);
-    else if (K == 27 && cout == 2) PCC_GS27(2);
-    else if (K == 27 && cout == 3) PCC_GS27(3);
-    else if (K == 27 && cout == 4) PCC_GS27(4);
+    if (K == 27 && al16 && cout == 1) PCC_GS27(1);
+    else if (K == 27 && al16 && cout == 2) PCC_GS27(2);
+    else if (K == 27 && al16 && cout == 3) PCC_GS27(3);
+    else if (K == 27 && al16 && cout == 4) PCC_GS27(4);
     else
 #undef PCC_GS27
         hipLaunchKernelGGL(gather_sum_kernel, dim3(blocks_for(n_out * cout, 256, 1 << 20)), dim3(256), 0, as_stream(stream),

@@ -329,6 +329,14 @@ def test_gather_sum_matches_sequential_sum_bitwise(pcc, cout, K, n_out):
     d_scores, d_nbr, d_bias = dev(scores), dev(nbr), dev(bias)
     check(lib().pcc_gather_sum_fwd(ptr(d_scores), K * cout, ptr(d_nbr), K, cout, ptr(d_bias), ptr(out), n_out, 1, stream()))
     assert np.array_equal(out.cpu().numpy(), want)
+    # a neighbour table that is only 4-byte aligned (the K = 27 kernel's 16-byte staging loads must not be used)
+    flat = torch.empty(n_out * K + 1, dtype=torch.int32, device=DEV)
+    flat[1:] = d_nbr.reshape(-1)
+    shifted = flat[1:]
+    assert shifted.data_ptr() % 16 == 4
+    out2 = torch.empty_like(out)
+    check(lib().pcc_gather_sum_fwd(ptr(d_scores), K * cout, shifted.data_ptr(), K, cout, ptr(d_bias), ptr(out2), n_out, 1, stream()))
+    assert torch.equal(out2, out)
 
 
 def test_gather_scatter_compact(pcc):
