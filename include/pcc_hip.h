@@ -126,6 +126,8 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
  * pcc_order_rows_by_mask, and position p computes output row order[p]; with order == NULL rows
  * run in natural order (group_mask32 may then be NULL = every offset executed).
  * film / residual / fout are always indexed by the output row, never by the position.
+ * MFMA path (also pcc_conv_fwd_bf16, pcc_conv_wgrad*): the gathered tensors (fin, dy) and
+ * w_packed must be 16-byte aligned — rows move by 16-byte LDS-DMA loads; PCC_ERR_ARG otherwise.
  * ------------------------------------------------------------------------------------- */
 int64_t pcc_conv_packed_elems(int32_t K, int32_t cin, int32_t cout);
 int pcc_conv_pack_weights(const float* w, int32_t K, int32_t cin, int32_t cout, float* w_packed,

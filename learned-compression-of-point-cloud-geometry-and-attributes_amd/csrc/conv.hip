@@ -928,6 +928,8 @@ int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint
     PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd_bf16: nbr == NULL needs K == 1 and n_in == n_out");
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd_bf16: bad activation %d", act);
     PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd_bf16: packed weights required");
+    PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(w_packed)) & 15) == 0,
+                "pcc_conv_fwd_bf16: fin and w_packed must be 16-byte aligned (16-byte LDS-DMA loads)");
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
     a.fin = reinterpret_cast<const float*>(fin); a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
@@ -982,6 +984,8 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
     hipStream_t st = as_stream(stream);
     if (cin % 32 == 0) {
         PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd: MFMA path (cin=%d) needs packed weights", cin);
+        PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(w_packed)) & 15) == 0,
+                    "pcc_conv_fwd: fin and w_packed must be 16-byte aligned (16-byte LDS-DMA loads)");
         // Row-tile height, measured on MI355X: 128-wide outputs run best with 64-row tiles (48 KB of LDS per
         // workgroup -> 3 workgroups per CU, twice the tiles per launch -> less tail loss on mid-size layers);
         // 64-wide outputs with 128-row tiles (half the weight-slab traffic per MFMA).  PCC_CONV_BM=64|128

@@ -437,6 +437,8 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
     if (cin % 32 == 0 && cout % 32 == 0) {
         PCC_REQUIRE((uint64_t)n_in * cin * 4 <= WG_OOB && (uint64_t)n_out * cout * 4 <= WG_OOB,
                     "pcc_conv_wgrad: operands of 4 GiB and more are not supported yet");
+        PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
+                    "pcc_conv_wgrad: fin and dy must be 16-byte aligned (16-byte LDS-DMA loads)");
         const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
         hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 8 * 1024 * sizeof(float), st, a);
     } else {
@@ -456,6 +458,8 @@ int pcc_conv_wgrad_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const ui
     PCC_REQUIRE(cin % 64 == 0 && cout % 64 == 0 && cin >= 64 && cout >= 64, "pcc_conv_wgrad_bf16: cin and cout must be multiples of 64 (got %d, %d)", cin, cout);
     PCC_REQUIRE(nbr != nullptr, "pcc_conv_wgrad_bf16: neighbour table required");
     PCC_REQUIRE((uint64_t)n_in * cin * 2 <= WG_OOB && (uint64_t)n_out * cout * 2 <= WG_OOB, "pcc_conv_wgrad_bf16: operands of 4 GiB and more are not supported");
+    PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
+                "pcc_conv_wgrad_bf16: fin and dy must be 16-byte aligned (16-byte LDS-DMA loads)");
     hipStream_t st = as_stream(stream);
     const int64_t elems = (int64_t)K * cin * cout;
     if (n_out <= 0) {
