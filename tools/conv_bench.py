@@ -13,7 +13,7 @@ from pcc_amd._lib import ptr, check
 dev = "cuda:0"
 L = pcc_amd.lib()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-shapes = [(128, 128), (64, 64), (128, 256)]
+shapes = [(128, 128), (64, 64), (128, 256)] if not os.environ.get("SHAPES") else [tuple(int(v) for v in s.split("x")) for s in os.environ["SHAPES"].split(",")]
 K = 27
 torch.manual_seed(0)
 for cin, cout in shapes:
