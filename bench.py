@@ -29,6 +29,7 @@ import numpy as np
 import torch
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+MFMA_BF16_PEAK_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16, dense (--bf16 runs only)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -48,6 +49,9 @@ def parse():
     ap.add_argument("--weights", default=None,
                     help="state_dict to load instead of the seeded initialisation (e.g. from tools/train.py); the headline "
                          "configuration is the seeded one")
+    ap.add_argument("--bf16", action="store_true",
+                    help="opt-in reduced-precision mode: bf16 operands on the wide convolutions (fp32 accumulation); NOT the "
+                         "headline configuration — the reference computes in fp32 and so does the default run")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -113,6 +117,8 @@ def main():
     if args.weights:
         model.load_state_dict(torch.load(args.weights, map_location=dev))
     model.update()
+    if args.bf16:
+        sp.set_infer_bf16(True)
 
     cfg = {"config1": syn.CONFIG1, "config2": syn.CONFIG2, "mid": dict(grid=256, radius=100.0, half_width=0.5)}[args.workload]
     cfg = dict(cfg)
@@ -244,8 +250,11 @@ def main():
                 traffic = tj["traffic_bytes_per_launch"]
                 traffic_src = ("profiles/r01_traffic_dominant_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                "this command, FETCH x2 gfx950 correction)")
-        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
+        peak = MFMA_BF16_PEAK_TFLOPS if "[bf16]" in dom_name else MFMA_F32_PEAK_TFLOPS
+        if "[bf16]" in dom_name:
+            traffic = traffic_src = None               # the PMC passes were taken on the fp32 kernel
+        roofline = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                     "traffic_unit": "bytes per launch (HBM, PMC)", "traffic_source": traffic_src,
                     "algorithmic_gather_bytes_per_launch": d["gather_bytes"] / d["launches"],
                     "launches_per_step": d["launches"] / args.steps,
@@ -311,7 +320,7 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if blocks_mode else "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": "bf16 operands on the wide convolutions, fp32 accumulation (opt-in mode, not the headline)" if args.bf16 else "f32",
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {cfg['grid']}^3 voxel sphere shell r={cfg['radius']}, N={N} points/frame, "
                                f"q=(0.5,0.5), configs/Ours.yaml, {'weights from ' + os.path.basename(args.weights) if args.weights else 'seeded random weights'}, in-memory compress+decompress, "

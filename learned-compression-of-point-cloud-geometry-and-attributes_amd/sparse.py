@@ -334,17 +334,24 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         K = ksize ** 3
     n_out = out_map.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
+    bf16 = INFER_BF16 and cin % 64 == 0 and x_feats.shape[0] * cin * 2 < 0xFFFFF000
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
-                         ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+    if bf16:
+        xb = x_feats.to(torch.bfloat16)
+        check(L.pcc_conv_fwd_bf16(ptr(xb), x_feats.shape[0], cin, ptr(layer.weights_bf16(out_channels)), ptr(bias), ptr(nbr),
+                                  ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+    else:
+        check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
+                             ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     if prof is not None:
         ev1.record()
-        prof.append((conv_kernel_name(cin, cout, n_out, nbr is not None), cin, cout, pairs if pairs is not None else n_out,
-                     n_out, ev0, ev1, gmask))
+        name = conv_kernel_name(cin, cout, n_out, nbr is not None)
+        prof.append((name.replace("conv_mfma_buf_kernel", "conv_mfma_buf_kernel[bf16]") if bf16 else name, cin, cout,
+                     pairs if pairs is not None else n_out, n_out, ev0, ev1, gmask))
     return out
 
 
@@ -379,6 +386,18 @@ NARROW_HEAD_MAX_COUT = 4
 # Spatial block size (log2, in voxels of the map's stride) inside which rows are ordered by neighbour
 # mask; -1 = order by mask over the whole map (best MFMA tile occupancy, least gather locality).
 ORDER_BLOCK_LOG2 = int(os.environ.get("PCC_ORDER_BLOCK_LOG2", "-1"))
+
+# Opt-in reduced-precision inference (never the default, never the headline number): convolutions whose input width
+# is a multiple of 64 take bf16 operands (features cast per layer, weights packed once) on v_mfma_f32_32x32x16_bf16
+# with fp32 accumulation, epilogue and outputs; narrow / thin layers and the entropy models stay fp32.  Encoder and
+# decoder must run in the same mode (the streams differ from the fp32 ones); PCC_INFER_BF16=1 / set_infer_bf16().
+INFER_BF16 = os.environ.get("PCC_INFER_BF16", "0") == "1"
+
+
+def set_infer_bf16(enabled):
+    global INFER_BF16
+    INFER_BF16 = bool(enabled)
+
 
 # Optional launch log for bench.py: a list that receives one tuple per convolution launch
 # (kernel class, cin, cout, pairs (device scalar or int), n_out, start event, end event).  The
@@ -459,6 +478,20 @@ class _ConvBase(nn.Module):
         res = (w, wp, b)
         self._packed["w"] = (key, res)
         return res
+
+    def weights_bf16(self, out_channels=None):
+        """bf16 MFMA packing of the kernel (opt-in reduced-precision inference), cached like weights()"""
+        key = ("bf16", self.kernel._version, self.kernel.data_ptr(), out_channels)
+        hit = self._packed.get("b")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w, _, _ = self.weights(out_channels)
+        K, cin, cout = w.shape
+        L = _lib.lib()
+        wpb = torch.empty(L.pcc_conv_packed_elems_bf16(K, cin, cout), dtype=torch.bfloat16, device=w.device)
+        check(L.pcc_conv_pack_weights_bf16(ptr(w), K, cin, cout, ptr(wpb), _lib.stream()))
+        self._packed["b"] = (key, wpb)
+        return wpb
 
     def narrow_weights(self, out_channels=None):
         """Kernel re-laid-out for the narrow-head path: [1, cin, K*cout] (+ MFMA packing), bias, K, cout."""

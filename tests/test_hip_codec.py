@@ -86,6 +86,49 @@ def test_decoder_reproduces_encoder_latents_bit_exactly(pcc, model):
     assert (points[0].cpu().numpy() == y.C.cpu().numpy()[oc.sort_order(y.C.cpu().numpy())]).all()
 
 
+def test_opt_in_bf16_inference_round_trips_and_tracks_fp32(pcc, model):
+    """PCC_INFER_BF16 / set_infer_bf16: bf16 operands on the wide convolutions.  Encoder and decoder in the same mode
+    reproduce each other's latents bit for bit (the decode would diverge otherwise); rate and distortion stay close
+    to the fp32 codec.  Not the default and not the headline configuration."""
+    from pcc_amd import sparse as sp
+    from pcc_amd.metrics import PointCloudMetric
+    pts, qc, qf = _inputs(pcc, dict(grid=64, radius=27.0, half_width=0.6))
+    x = torch.from_numpy(pts).to(DEV)
+
+    def code():
+        Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+        strings, shape, k, coords = model.compress(x, Q)
+        rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+        m, _ = PointCloudMetric(x, rec, resolution=63).compute_pointcloud_metrics(drop_duplicates=True)
+        return pcc.utils.count_bits(strings) / pts.shape[0], m["sym_psnr_mse"], m["sym_y_psnr"], rec
+
+    ref = code()
+    assert not sp.INFER_BF16
+    sp.set_infer_bf16(True)
+    try:
+        got = code()
+        again = code()
+        # latents: encoder-side y_hat == decoder-side y_hat, in bf16 mode too
+        N = pts.shape[0]
+        coords = torch.cat([torch.zeros((N, 1), device=DEV, dtype=torch.int32), x[:, :3].to(torch.int32)], dim=1)
+        feats = torch.cat([torch.ones((N, 1), device=DEV), x[:, 3:6]], dim=1)
+        inp = pcc.SparseTensor(feats, coordinate_map=pcc.CoordMap(coords, 1, nbatch=1))
+        Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+        em = model.entropy_model
+        y, _, _ = model.g_a(inp, Q)
+        _, strings, shape = em.compress(y)
+        y_hat_enc, _, _ = em(y)
+        c8 = pcc.CoordMap(y.C, 8, nbatch=1)
+        y_hat_dec, _ = em.decompress([c8, c8.down().down()], strings, shape)
+        idx = y_hat_dec.map.lookup(y.C).long()
+        assert torch.equal(y_hat_dec.F[idx], y_hat_enc.F)
+    finally:
+        sp.set_infer_bf16(False)
+    assert torch.equal(got[3], again[3])                                  # deterministic
+    assert abs(got[0] - ref[0]) < 0.05 * ref[0], (got[0], ref[0])         # bpp within 5 %
+    assert abs(got[1] - ref[1]) < 1.0 and abs(got[2] - ref[2]) < 0.5, (got[:3], ref[:3])   # dB
+
+
 def test_file_mode_round_trip(pcc, model, tmp_path):
     pts, qc, qf = _inputs(pcc, dict(grid=32, radius=15.0, half_width=0.875))
     x = torch.from_numpy(pts).to(DEV)
