@@ -41,6 +41,15 @@ __global__ __launch_bounds__(256) void map_transpose_kernel(const int32_t* __res
     atomicOr(&mask_t[i], 1u << k);
 }
 
+// Workgroups are dispatched in blockIdx order and an offset's pair count falls with its distance from the centre
+// (the centre offset pairs every row, a corner offset a third of them): 3x3x3 kernels hand out the centre first,
+// then faces, edges, corners, so that the launch ends on its cheapest workgroups.
+__device__ __forceinline__ int wgrad_offset_of(int slot, int K) {
+    constexpr unsigned char heavy_first[27] = {13, 4, 10, 12, 14, 16, 22, 1, 3, 5, 7, 9, 11, 15, 17, 19, 21, 23, 25,
+                                               0, 2, 6, 8, 18, 20, 24, 26};
+    return K == 27 ? heavy_first[slot] : slot;
+}
+
 struct WgradArgs {
     const float* fin;
     const float* dy;
@@ -62,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
     const int r = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);
     const int SPLIT = a.split;
-    const int k = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
+    const int k = wgrad_offset_of(blockIdx.x / SPLIT, a.K), s = blockIdx.x % SPLIT;
     const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
     const int cbi = min(4, (a.cin - cin0) / 32), cbo = min(4, (a.cout - cout0) / 32);     // chunks present in this block
     // Blocks of at most 64 x 64 (64-channel layers) would leave three of the four waves without a tile and
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
     const int r = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);
     const int SPLIT = a.split;
-    const int k = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
+    const int k = wgrad_offset_of(blockIdx.x / SPLIT, a.K), s = blockIdx.x % SPLIT;
     const int cin0 = blockIdx.y * 128, cout0 = blockIdx.z * 128;
     const int cbi = min(2, (a.cin - cin0) / 64), cbo = min(2, (a.cout - cout0) / 64);     // 64-channel chunks present
     const int TM = 2 * cbi, TN = 2 * cbo, NTILES = TM * TN;
