@@ -264,6 +264,18 @@ def main():
                     # the same launches seen from the memory side: measured HBM bytes (PMC) over the measured duration
                     "hbm_gbps": None if traffic is None else traffic / (d["ms"] / d["launches"] * 1e-3) / 1e9,
                     "hbm_peak_gbps": 8000.0}
+        # the peak assumes 2.4 GHz; the delivered clock of this kernel class under load was measured in a separate
+        # rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace pass of this command (profiles/r01_clock_under_load.json)
+        cfile = os.path.join(ROOT, "profiles", "r01_clock_under_load.json")
+        if args.workload == "config2" and "[bf16]" not in dom_name and os.path.exists(cfile):
+            with open(cfile) as f:
+                cj = json.load(f)["bench_config2_frame"]
+            for key, val in cj.items():
+                if key.replace(" ", "").startswith(dom_name.replace(" ", "").rstrip(">")) and "mean_clock_GHz" in val:
+                    roofline["peak_assumes_clock_ghz"] = 2.4
+                    roofline["delivered_clock_ghz"] = val["mean_clock_GHz"]
+                    roofline["frac_at_delivered_clock"] = achieved / (peak * val["mean_clock_GHz"] / 2.4)
+                    roofline["clock_source"] = "profiles/r01_clock_under_load.json (GRBM_GUI_ACTIVE / launch duration)"
     if args.breakdown and rank == 0:
         tot_ms = sum(c["ms"] for c in classes.values())
         for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
