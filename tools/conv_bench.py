@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Development aid: time pcc_conv_fwd alone on synthetic neighbour tables to separate MFMA-pipe
 efficiency from gather latency.  Patterns: 'local' (neighbours = nearby rows, L2-resident),
-'random' (uniform random rows, HBM-resident), 'same' (every neighbour = row 0)."""
+'random' (uniform random rows, HBM-resident), 'same' (every neighbour = row 0), 'streams' (27 sequential streams),
+'runs32' (runs of 32 consecutive rows at random places)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -31,6 +32,11 @@ for cin, cout in shapes:
         "same": torch.zeros(n, K, dtype=torch.int32, device=dev),
         "local": ((rows + torch.arange(K, device=dev).unsqueeze(0) * 3) % n).to(torch.int32),
         "random": torch.randint(0, n, (n, K), dtype=torch.int32, device=dev),
+        # 27 sequential streams far apart (no L2 reuse between offsets, but consecutive rows gather consecutive rows)
+        "streams": ((rows + torch.arange(K, device=dev).unsqueeze(0) * (n // K)) % n).to(torch.int32),
+        # runs of 32 consecutive rows at random places (what a physically mask-sorted layout might give)
+        "runs32": (((torch.randint(0, n // 32, (n // 32 + 1, K), device=dev).repeat_interleave(32, dim=0)[:n] * 32)
+                    + (rows % 32)) % n).to(torch.int32),
     }
     for name, nbr in pats.items():
         nbr = nbr.contiguous()
