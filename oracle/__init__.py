@@ -19,4 +19,13 @@ facts the reference itself fixes (parameter count 31,469,942 <-> README.md:125,
 channel order utils.py:439), (iii) C / pure-Python rANS twins that must agree
 byte for byte, and (iv) committed golden vectors under tests/golden/ generated
 by tests/golden/make_golden.py.
+
+The ONE reference-generated fixture is tests/golden/bjontegaard_ref.json: the
+reference's own metrics/bjontegaard.py (importable in the build container:
+numpy / scipy / matplotlib only) evaluated on RD rows of its
+results/Ours/test.csv by tests/golden/make_bd_golden.py.  It pins the product's
+Bjontegaard_Model / Bjontegaard_Delta, NOT the codec:
+the codec's arithmetic stays "parity unpinned" — that is the environment's
+limit (no MinkowskiEngine / compressai), and no stand-in modules are written to
+get around it.
 """

@@ -34,6 +34,42 @@ def test_bjontegaard_identities_and_known_shift(pcc):
     assert np.allclose(m1.evaluate(r), d, atol=1e-9)
 
 
+def test_bjontegaard_matches_the_reference_module(pcc):
+    """tests/golden/bjontegaard_ref.json was produced by the reference's own metrics/bjontegaard.py on RD rows of
+    its results/Ours/test.csv (tests/golden/make_bd_golden.py, build container only): the one reference-generated
+    fixture of this repository.  It pins the BD half of SURVEY.md 8f rank 3 — not the codec."""
+    import json
+    import os
+    from pcc_amd.metrics import Bjontegaard_Delta, Bjontegaard_Model
+    with open(os.path.join(os.path.dirname(__file__), "golden", "bjontegaard_ref.json")) as f:
+        gold = json.load(f)
+    models = {}
+    for key, want in gold["models"].items():
+        name, metric = key.split("/")
+        c = gold["curves"][name]
+        m = models[key] = Bjontegaard_Model(c["bpp"], c[metric])
+        assert np.allclose(m.parameters_PSNR, want["parameters_PSNR"], rtol=1e-9, atol=1e-9), key
+        assert np.allclose(m.parameters_Rate, want["parameters_Rate"], rtol=1e-9, atol=1e-12), key
+        assert np.allclose([m.evaluate(r) for r in want["probe_rates"]], want["evaluate"], rtol=0, atol=1e-9), key
+        assert np.allclose([m.evaluate_rate(d) for d in want["probe_psnr"]], want["evaluate_rate"], rtol=0, atol=1e-9), key
+        _, _, xs, ys = m.get_plot_data()
+        assert len(xs) == 100 and len(ys) == 100
+        assert np.allclose([xs[0], xs[-1]], want["plot_x_first_last"], atol=1e-12)
+        assert np.allclose([ys[0], ys[-1]], want["plot_y_first_last"], atol=1e-9)
+    bd = Bjontegaard_Delta()
+    assert len(gold["deltas"]) == 12
+    for d in gold["deltas"]:
+        m1, m2 = models[f"{d['model1']}/{d['metric']}"], models[f"{d['model2']}/{d['metric']}"]
+        assert bd.compute_BD_PSNR(m1, m2) == pytest.approx(d["BD_PSNR"], abs=1e-9), d
+        assert bd.compute_BD_Rate(m1, m2) == pytest.approx(d["BD_Rate"], abs=1e-9), d
+    ex = gold["module_example"]                      # the example in the reference module's __main__
+    m1, m2 = Bjontegaard_Model(ex["bitrates1"], ex["d1"]), Bjontegaard_Model(ex["bitrates2"], ex["d1"])
+    assert bd.compute_BD_PSNR(m1, m2) == pytest.approx(ex["BD_PSNR_12"], abs=1e-9)
+    assert bd.compute_BD_Rate(m1, m2) == pytest.approx(ex["BD_Rate_12"], abs=1e-9)
+    assert bd.compute_BD_PSNR(m2, m1) == pytest.approx(ex["BD_PSNR_21"], abs=1e-9)
+    assert bd.compute_BD_Rate(m2, m1) == pytest.approx(ex["BD_Rate_21"], abs=1e-9)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,jitter", [(0, 0), (1, 1), (2, 3)])
 def test_metrics_match_oracle_both_modes(pcc, seed, jitter):
