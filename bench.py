@@ -33,6 +33,29 @@ MFMA_BF16_PEAK_TFLOPS = 2516.6    # v_mfma_f32_32x32x16_bf16, dense (--bf16 runs
 HBM_PEAK_GBS = 8000.0
 
 
+def latest_profile(stem):
+    """newest committed profiles/rNN_<stem>.json (named per round); its path is added under the key _file"""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{stem}.json")))
+    if not hits:
+        return None
+    with open(hits[-1]) as f:
+        j = json.load(f)
+    j["_file"] = os.path.relpath(hits[-1], ROOT)
+    return j
+
+
+def kernel_source_sha256():
+    """hash of the sources the convolution kernels are built from: a profile taken on other sources is stale"""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "learned-compression-of-point-cloud-geometry-and-attributes_amd", "csrc")
+    for name in ("conv.hip", "common.h", "Makefile"):
+        with open(os.path.join(base, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +69,9 @@ def parse():
                     help="N > 1 sharding: one frame per rank (weak scaling, the default) or the cubes of ONE frame "
                          "spread over the ranks (strong scaling; different numbers than whole-frame coding, SURVEY.md 8e)")
     ap.add_argument("--block", type=int, default=512, help="cube edge of --partition blocks")
+    ap.add_argument("--no-blocks-record", action="store_true",
+                    help="skip the strong-scaling 'blocks' sub-record (one frame cut into cubes over the ranks) that "
+                         "a frames run reports beside its value")
     ap.add_argument("--weights", default=None,
                     help="state_dict to load instead of the seeded initialisation (e.g. from tools/train.py); the headline "
                          "configuration is the seeded one")
@@ -57,9 +83,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(state_dict, sample):
-    """The oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload."""
-    from oracle.codec import Codec
+def cpu_baseline(model, state_dict, sample, dev):
+    """The oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload; the HIP codec then
+    codes the SAME frame with the same weights and both results go into ``parity`` (the oracle run is the checker
+    here, never the thing measured as ``value``)."""
+    from oracle.codec import Codec, count_bits
+    from oracle.metrics import pc_metrics
     import pcc_amd
     grid, radius, hw = sample.split(",")
     pts = pcc_amd.synthetic.sphere_shell(int(grid), float(radius), float(hw))
@@ -78,13 +107,31 @@ def cpu_baseline(state_dict, sample):
     strings, shape, k, coords = codec.compress(pts, qc, qf)
     t1 = time.time()
     print(f"[bench] cpu_baseline: encode {t1 - t0:.1f} s", file=sys.stderr, flush=True)
-    codec.decompress(coords, strings, shape, k)
+    o_rec = codec.decompress(coords, strings, shape, k)
     t2 = time.time()
     print(f"[bench] cpu_baseline: decode {t2 - t1:.1f} s", file=sys.stderr, flush=True)
     n = pts.shape[0]
+    # the HIP path on the same frame
+    x = torch.from_numpy(pts).to(dev)
+    Q = pcc_amd.SparseTensor(coordinates=torch.from_numpy(qc).to(dev), features=torch.from_numpy(qf).to(dev), device=dev)
+    h_strings, h_shape, h_k, h_coords = model.compress(x, Q)
+    h_rec = model.decompress(coordinates=h_coords, strings=h_strings, shape=h_shape, k=h_k).cpu().numpy()
+    res = int(grid) - 1
+    hm, om = pc_metrics(pts, h_rec, res), pc_metrics(pts, o_rec, res)
+    flips = len(set(map(tuple, h_rec[:, :3].tolist())) ^ set(map(tuple, o_rec[:, :3].tolist())))
+    parity = {"frame": f"{grid}^3 shell, N={n}", "structure_equal": bool(h_shape == shape and h_k == k),
+              "bpp": {"hip": count_bits(h_strings) / n, "oracle": count_bits(strings) / n},
+              "d1_psnr_db": {"hip": float(hm["sym_psnr_mse"]), "oracle": float(om["sym_psnr_mse"])},
+              "y_psnr_db": {"hip": float(hm["sym_y_psnr"]), "oracle": float(om["sym_y_psnr"])},
+              "decoded_voxels_differing": flips,
+              "metric_resolution": res}
+    parity["abs_diff"] = {"bpp": abs(parity["bpp"]["hip"] - parity["bpp"]["oracle"]),
+                          "d1_psnr_db": abs(parity["d1_psnr_db"]["hip"] - parity["d1_psnr_db"]["oracle"]),
+                          "y_psnr_db": abs(parity["y_psnr_db"]["hip"] - parity["y_psnr_db"]["oracle"])}
     return {"value": n / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
             "sample": f"one {grid}^3 sphere-shell frame, N={n} points, q=(0.5,0.5), same weights; "
-                      f"t_enc={t1 - t0:.2f}s t_dec={t2 - t1:.2f}s (torch-CPU sgemm + C rANS oracle)"}
+                      f"t_enc={t1 - t0:.2f}s t_dec={t2 - t1:.2f}s (torch-CPU sgemm + C rANS oracle)",
+            "parity": parity}
 
 
 def main():
@@ -208,6 +255,57 @@ def main():
     else:
         n_total = N
 
+    # ---- north_star's whole-frame mode beside the frames number: ONE frame (rank 0's) cut into cubes that are spread
+    # over the ranks by point count (strong scaling; different numbers than whole-frame coding) ----
+    blocks_record = None
+    if not blocks_mode and not args.no_blocks_record:
+        if rank == 0:
+            xb, qb = x, q_feats
+        else:
+            cfg0 = dict(cfg)
+            cfg0["radius"] = cfg["radius"] + 0.25 * rank
+            p0 = syn.sphere_shell(**cfg0)
+            xb = torch.from_numpy(p0).to(dev)
+            qb = torch.from_numpy(syn.uniform_qmap(p0[:, :3], 0.5, 0.5)[1]).to(dev)
+        nb_frame = xb.shape[0]
+        b_steps = max(1, min(3, args.steps))
+
+        def blocks_step():
+            _, parts_, units = par.compress_blocks(model, xb, qb, args.block, rank, world)
+            torch.cuda.synchronize()
+            rec_ = par.decompress_blocks(model, units) if units else None
+            payload = b"".join(par.pack_items_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
+            if world > 1:
+                par.all_gather_bitstreams(payload, cdev)
+            return units, parts_, (0 if rec_ is None else rec_.shape[0])
+
+        blocks_step()                                               # warm-up: kernel maps of the cube sizes, caches
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        for _ in range(b_steps):
+            b_units, b_parts, b_dec = blocks_step()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        b_elapsed = time.perf_counter() - tb0
+        b_bits = sum(pcc_amd.utils.count_bits(u[1]) for u in b_units)
+        if dist is not None:
+            tb = torch.tensor([b_elapsed], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+            b_elapsed = float(tb.item())
+            agg = torch.tensor([b_bits, b_dec], dtype=torch.int64, device=cdev)
+            dist.all_reduce(agg)
+            b_bits, b_dec = int(agg[0].item()), int(agg[1].item())
+        blocks_record = {"value": nb_frame * b_steps / b_elapsed / 1e6, "unit": "Mpoints/s", "scaling": "strong",
+                         "steps": b_steps, "ms_per_step": b_elapsed / b_steps * 1e3, "block": args.block,
+                         "cubes": int(sum(len(p_) for p_ in b_parts)), "cubes_per_rank": [len(p_) for p_ in b_parts],
+                         "bpp": b_bits / nb_frame, "decoded_points": b_dec, "points_per_frame": nb_frame,
+                         "note": "one frame per step, its cubes coded as batch items of one compress call per rank "
+                                 "(per-item k and top-k), containers all-gathered; a different partition gives "
+                                 "different numbers than whole-frame coding (parity target: the oracle on the same items)"}
+
     # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
     classes = {}
     pop_cache = {}
@@ -242,14 +340,14 @@ def main():
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
         # same command, reduced by tools/pmc_traffic.py and committed under profiles/
         traffic, traffic_src = None, None
-        tfile = os.path.join(ROOT, "profiles", "r01_traffic_dominant_kernel.json")
-        if args.workload == "config2" and os.path.exists(tfile):
-            with open(tfile) as f:
-                tj = json.load(f)
-            if tj["kernel"] in dom_name:
-                traffic = tj["traffic_bytes_per_launch"]
-                traffic_src = ("profiles/r01_traffic_dominant_kernel.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                               "this command, FETCH x2 gfx950 correction)")
+        tj = latest_profile("traffic_dominant_kernel")
+        if args.workload == "config2" and tj is not None and tj["kernel"] in dom_name:
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_src = {"file": tj["_file"], "taken_at_commit": tj.get("commit"),
+                           "command": tj.get("command"),
+                           "kernel_source_unchanged_since": tj.get("kernel_source_sha256") == kernel_source_sha256(),
+                           "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 "
+                                  "correction (tools/pmc_traffic.py); replayed from the committed file, not measured in this run"}
         peak = MFMA_BF16_PEAK_TFLOPS if "[bf16]" in dom_name else MFMA_F32_PEAK_TFLOPS
         if "[bf16]" in dom_name:
             traffic = traffic_src = None               # the PMC passes were taken on the fp32 kernel
@@ -266,16 +364,15 @@ def main():
                     "hbm_peak_gbps": 8000.0}
         # the peak assumes 2.4 GHz; the delivered clock of this kernel class under load was measured in a separate
         # rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace pass of this command (profiles/r01_clock_under_load.json)
-        cfile = os.path.join(ROOT, "profiles", "r01_clock_under_load.json")
-        if args.workload == "config2" and "[bf16]" not in dom_name and os.path.exists(cfile):
-            with open(cfile) as f:
-                cj = json.load(f)["bench_config2_frame"]
-            for key, val in cj.items():
+        cj = latest_profile("clock_under_load")
+        if args.workload == "config2" and "[bf16]" not in dom_name and cj is not None:
+            for key, val in cj.get("bench_config2_frame", {}).items():
                 if key.replace(" ", "").startswith(dom_name.replace(" ", "").rstrip(">")) and "mean_clock_GHz" in val:
                     roofline["peak_assumes_clock_ghz"] = 2.4
                     roofline["delivered_clock_ghz"] = val["mean_clock_GHz"]
                     roofline["frac_at_delivered_clock"] = achieved / (peak * val["mean_clock_GHz"] / 2.4)
-                    roofline["clock_source"] = "profiles/r01_clock_under_load.json (GRBM_GUI_ACTIVE / launch duration)"
+                    roofline["clock_source"] = {"file": cj["_file"], "taken_at_commit": cj.get("commit"),
+                                                "how": "GRBM_GUI_ACTIVE / launch duration, separate --pmc pass"}
     if args.breakdown and rank == 0:
         tot_ms = sum(c["ms"] for c in classes.values())
         for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
@@ -346,11 +443,13 @@ def main():
         "conv_gflop_per_step": sum(c["flops"] for c in classes.values()) / args.steps / 1e9,
         "roofline": roofline,
     }
+    if blocks_record is not None:
+        out["blocks"] = blocks_record
     if file_mode is not None:
         out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {n_: t.detach().cpu() for n_, t in model.state_dict().items()}
-        out["cpu_baseline"] = cpu_baseline(sd, args.cpu_sample)
+        out["cpu_baseline"] = cpu_baseline(model, sd, args.cpu_sample, dev)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

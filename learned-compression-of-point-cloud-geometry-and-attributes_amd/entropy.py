@@ -226,7 +226,10 @@ class EntropyBottleneck(_EntropyModelBase):
 
     def loss(self):
         """aux loss (reference: model/model.py:40-47, train.py:209)."""
-        logits = self._logits_cumulative(self._density_params(), self.quantiles)
+        # compressai evaluates the density with stop_gradient=True here: only ``quantiles`` receive a gradient
+        mats, biases, factors = self._density_params()
+        frozen = ([m.detach() for m in mats], [b.detach() for b in biases], [f.detach() for f in factors])
+        logits = self._logits_cumulative(frozen, self.quantiles)
         return torch.abs(logits - self.target).sum()
 
     def medians(self):

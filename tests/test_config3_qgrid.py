@@ -1,0 +1,86 @@
+"""BASELINE config 3 on the GPU against the CPU oracle: four frames (scaled-down stand-ins for the four 8iVFB
+sequences) x the four (q_g, q_a) pairs of /root/reference/plot.py:31-32, plus non-uniform quality maps
+(the gradient map of data/q_map.py:245-259, the view-dependent and region-of-interest maps of
+evaluate_view_dep.py:207-260).  The q-map conditions every FiLM head and is itself coded through z
+(entropy_models.py:341-414), so each pair exercises different rates, different k-independent paths and
+different beta/gamma on the same kernels.
+
+Tolerances: bpp 2e-3 relative (rounding-boundary symbol flips), D1 / Y-PSNR 1e-3 dB (BASELINE.json) with the
+one-voxel-flip bound of tests/_parity.py where the decoded voxel sets differ.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle.codec import count_bits
+from oracle.metrics import pc_metrics
+from _parity import assert_psnr_parity, voxel_flips
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+Q_GRID = [(0.05, 0.1), (0.1, 0.2), (0.2, 0.4), (0.4, 0.8)]              # (q_g, q_a), plot.py:31-32
+# radii in the ratio of the rd_sweep frames (247 : 255 : 261.5 : 294.5 at 1024^3), 96^3 grid
+FRAMES = {"redandblack~": 36.0, "loot~": 37.25, "longdress~": 38.0, "soldier~": 43.0}
+
+
+@pytest.fixture(scope="module")
+def model(pcc):
+    m = pcc.synthetic.make_model(0, DEV)
+    m.update()
+    return m
+
+
+def _compare(pcc, model, oracle_codec, pts, qc, qf, tag):
+    x = torch.from_numpy(pts).to(DEV)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    strings, shape, k, coords = model.compress(x, Q)
+    o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
+    assert shape == o_shape and k == o_k, tag
+    assert set(map(tuple, coords.cpu().numpy().tolist())) == set(map(tuple, o_coords.tolist())), tag
+    N = pts.shape[0]
+    bpp, o_bpp = count_bits(strings) / N, count_bits(o_strings) / N
+    assert abs(bpp - o_bpp) <= 2e-3 * o_bpp + 1e-3, (tag, bpp, o_bpp)
+    rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k).cpu().numpy()
+    o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+    assert rec.shape == o_rec.shape == (N, 6), tag
+    flips = voxel_flips(rec, o_rec)
+    assert flips <= max(4, int(2e-3 * N)), (tag, flips)
+    m, om = pc_metrics(pts, rec), pc_metrics(pts, o_rec)
+    assert_psnr_parity(m, om, flips, N, tag)        # 1e-3 dB; tests/_parity.py states the one-voxel-flip bound
+    return bpp, o_bpp, m, om, flips
+
+
+@pytest.mark.parametrize("frame", list(FRAMES))
+def test_q_grid_vs_oracle(pcc, model, oracle_codec, frame):
+    syn = pcc.synthetic
+    pts = syn.sphere_shell(grid=96, radius=FRAMES[frame], half_width=0.5, noise=0.02)
+    rates = []
+    for q_g, q_a in Q_GRID:
+        qc, qf = syn.uniform_qmap(pts[:, :3], q_g, q_a)
+        bpp, o_bpp, m, om, flips = _compare(pcc, model, oracle_codec, pts, qc, qf, (frame, q_g, q_a))
+        rates.append((bpp, o_bpp))
+    # the four operating points are four different codings, on the GPU exactly as in the oracle
+    assert len({round(r[0], 6) for r in rates}) == 4 and len({round(r[1], 6) for r in rates}) == 4
+
+
+def test_non_uniform_quality_maps_vs_oracle(pcc, model, oracle_codec):
+    """per-point q: gradient along an axis (training-time generator), view-dependent fall-off and a
+    region of interest (evaluate_view_dep.py)"""
+    from pcc_amd import q_map as qm
+    syn = pcc.synthetic
+    pts = syn.sphere_shell(grid=96, radius=38.0, half_width=0.5, noise=0.02)
+    N = pts.shape[0]
+    coords = np.concatenate([np.zeros((N, 1), np.float32), pts[:, :3]], axis=1)
+    cmap = pcc.CoordMap(torch.from_numpy(coords.astype(np.int32)).to(DEV), 1, nbatch=1)
+    cases = {
+        "gradient_x": qm.gradient_map(cmap, 1),
+        "gradient_z_narrow": qm.gradient_map(cmap, 3, 0.1, 0.6),
+        "view_dependent": qm.view_dependent_map(cmap, 0.4, 0.8, 2, 20.0, 80.0),
+        "roi": qm.roi_map(cmap, 0.4, 0.8, 1, 48),
+    }
+    for tag, Q in cases.items():
+        qf = Q.F.cpu().numpy()
+        assert qf.shape == (N, 2) and qf.min() >= 0.0 and qf.max() <= 1.0
+        assert np.unique(qf[:, 0]).size > 1                      # genuinely non-uniform
+        _compare(pcc, model, oracle_codec, pts, coords, qf, tag)

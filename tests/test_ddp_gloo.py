@@ -71,6 +71,80 @@ def test_bucketed_gradient_average_world2(tmp_path):
         assert open(os.path.join(str(tmp_path), f"ok{r}")).read() == "1"
 
 
+def _aux_worker(rank, world, port, out_dir):
+    """the bottleneck optimiser of tools/train.py (train.py:205-211 of the reference) under data parallelism: main
+    parameters see rank-dependent gradients, the .quantiles parameters go through their own reducer, and after a
+    few steps update() must build IDENTICAL CDF tables on every rank"""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import hashlib
+    import pcc_amd                                                  # noqa: F401  (import alias of the package)
+    from pcc_amd.entropy import EntropyBottleneck
+    from pcc_amd.parallel import GradBucketReducer
+    torch.manual_seed(0)
+    eb = EntropyBottleneck(8)                                         # same initial state on every rank
+    params = [p for n, p in eb.named_parameters() if not n.endswith("quantiles")]
+    aux_params = [p for n, p in eb.named_parameters() if n.endswith("quantiles")]
+    opt, aux_opt = torch.optim.Adam(params, lr=1e-2), torch.optim.Adam(aux_params, lr=5e-2)
+    red, aux_red = GradBucketReducer(params), GradBucketReducer(aux_params)
+    for step in range(5):
+        g = torch.Generator().manual_seed(100 * step + rank)         # ranks see different data
+        v = torch.randn(1, 8, 40 + 8 * rank, generator=g) * (3.0 + rank)
+        opt.zero_grad(set_to_none=True)
+        aux_opt.zero_grad(set_to_none=True)
+        _, lik = eb(v, training=True)
+        (-torch.log2(lik).mean()).backward()
+        red.finish()
+        opt.step()
+        aux = eb.loss()
+        aux.backward()
+        aux_red.finish()
+        aux_opt.step()
+    red.close(); aux_red.close()
+    eb.update(force=True)
+    cdf, length, offset = eb.tables()
+    h = hashlib.sha256()
+    import numpy as np
+    for t in (cdf, length, offset, eb.quantiles.detach()):
+        h.update(np.ascontiguousarray(t.cpu().numpy() if torch.is_tensor(t) else t).tobytes())
+    with open(os.path.join(out_dir, f"tables{rank}"), "w") as f:
+        f.write(h.hexdigest())
+    dist.destroy_process_group()
+
+
+def test_bottleneck_quantiles_stay_identical_across_ranks(tmp_path):
+    """without averaging the aux gradients the EB quantiles drift per rank and ranks would code
+    with different CDF tables"""
+    world, port = 2, _free_port()
+    mp.spawn(_aux_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    digests = [open(os.path.join(str(tmp_path), f"tables{r}")).read() for r in range(world)]
+    assert len(digests[0]) == 64 and digests[0] == digests[1]
+
+
+def test_aux_loss_matches_oracle_and_only_reaches_quantiles():
+    """model/model.py:40-47 -> compressai EntropyBottleneck.loss(): |logits_cumulative(quantiles) - target| summed,
+    density parameters held fixed (stop_gradient)"""
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import pcc_amd                                                  # noqa: F401
+    from pcc_amd.entropy import EntropyBottleneck
+    from oracle.entropy import EntropyBottleneck as OracleEB
+    torch.manual_seed(3)
+    eb = EntropyBottleneck(16)
+    with torch.no_grad():
+        eb.quantiles.add_(torch.randn_like(eb.quantiles) * 0.7)
+        for i in range(5):
+            getattr(eb, f"_matrix{i}").add_(torch.randn_like(getattr(eb, f"_matrix{i}")) * 0.3)
+    loss = eb.loss()
+    loss.backward()
+    for n, p in eb.named_parameters():
+        assert (p.grad is not None) == n.endswith("quantiles"), n
+    sd = {k: v.detach() for k, v in eb.state_dict().items()}
+    want = float(OracleEB(sd).aux_loss())
+    assert float(loss.detach()) == pytest.approx(want, rel=1e-5)
+
+
 def test_single_process_is_identity():
     sys.path.insert(0, ROOT)
     from pcc_amd.parallel import GradBucketReducer

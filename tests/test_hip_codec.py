@@ -13,6 +13,7 @@ import torch
 from oracle import coords as oc
 from oracle.codec import count_bits
 from oracle.metrics import pc_metrics
+from _parity import assert_psnr_parity, voxel_flips
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -55,11 +56,10 @@ def test_compress_decompress_vs_oracle(pcc, model, oracle_codec, cfg):
     o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
     assert rec.shape == o_rec.shape == (k[2][0], 6)
     m, om = pc_metrics(pts, rec), pc_metrics(pts, o_rec)
-    for key in ("sym_psnr_mse", "sym_y_psnr"):
-        assert abs(m[key] - om[key]) <= 1e-3 + 2e-2 * (cfg["grid"] <= 32), (key, m[key], om[key])   # tolerance in dB
     # geometry: the decoded voxel sets agree except for top-k flips on near-ties
-    a, b = set(map(tuple, rec[:, :3].tolist())), set(map(tuple, o_rec[:, :3].tolist()))
-    assert len(a ^ b) <= max(4, int(2e-3 * len(a))), len(a ^ b)
+    flips = voxel_flips(rec, o_rec)
+    assert flips <= max(4, int(2e-3 * N)), flips
+    assert_psnr_parity(m, om, flips, N, cfg)         # 1e-3 dB (+ the one-voxel-flip bound of tests/_parity.py)
 
 
 def test_decoder_reproduces_encoder_latents_bit_exactly(pcc, model):
@@ -209,7 +209,7 @@ def test_block_partition_mode_vs_oracle_with_same_partition(pcc, model, oracle_c
     assert rec.shape == o_rec.shape == (pts.shape[0], 6)
     assert abs(bits - o_bits) <= 3e-3 * o_bits + 64
     m, om = pc_metrics(pts, rec), pc_metrics(pts, o_rec)
-    assert abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]) <= 2e-2 and abs(m["sym_y_psnr"] - om["sym_y_psnr"]) <= 2e-2
+    assert_psnr_parity(m, om, voxel_flips(rec, o_rec), pts.shape[0], "cubes")
 
 
 def test_blocks_as_batch_items_vs_oracle(pcc, model, oracle_codec):
@@ -240,7 +240,7 @@ def test_blocks_as_batch_items_vs_oracle(pcc, model, oracle_codec):
     for i in range(len(blocks)):                                                # every item decodes to its own count
         assert int((rec_item == i).sum()) == len(rows[blocks[i]])
     m, om = pc_metrics(sub, rec), pc_metrics(sub, o_rec)
-    assert abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]) <= 2e-2 and abs(m["sym_y_psnr"] - om["sym_y_psnr"]) <= 2e-2
+    assert_psnr_parity(m, om, voxel_flips(rec, o_rec), sub.shape[0], "batch items")
     with pytest.raises(ValueError):
         Q = pcc.SparseTensor(coordinates=torch.from_numpy(o_qc).to(DEV), features=torch.from_numpy(qf[sel]).to(DEV), device=DEV)
         model.compress(torch.from_numpy(sub).to(DEV), Q, path="/tmp/never_written.bin", batch=torch.from_numpy(item).to(DEV))

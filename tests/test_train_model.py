@@ -259,3 +259,20 @@ def test_overfitting_one_frame_learns_it(pcc):
     rec = model.decompress(coordinates=c8, strings=strings, shape=shape, k=k)
     res, _ = PointCloudMetric(x, rec, resolution=63).compute_pointcloud_metrics(drop_duplicates=True)
     assert res["sym_psnr_mse"] > 55.0 and res["sym_y_psnr"] > 22.0, (res["sym_psnr_mse"], res["sym_y_psnr"])
+    # the same TRAINED weights through the CPU oracle: learnt occupancy logits are far from ties and the
+    # reconstruction is a real cloud — the regime the seeded-weight parity tests do not reach
+    from oracle.codec import Codec, count_bits
+    from oracle.metrics import pc_metrics
+    oracle = Codec({n: t.detach().cpu() for n, t in model.state_dict().items()})
+    oracle.update()
+    o_strings, o_shape, o_k, o_c8 = oracle.compress(pts, qc, qf)
+    assert shape == o_shape and k == o_k
+    assert set(map(tuple, c8.cpu().numpy().tolist())) == set(map(tuple, o_c8.tolist()))
+    o_rec = oracle.decompress(o_c8, o_strings, o_shape, o_k)
+    bits, o_bits = count_bits(strings), count_bits(o_strings)
+    assert abs(bits - o_bits) <= 2e-3 * o_bits + 64, (bits, o_bits)
+    got, want = pc_metrics(pts, rec.cpu().numpy(), 63), pc_metrics(pts, o_rec, 63)
+    from _parity import assert_psnr_parity, voxel_flips
+    flips = voxel_flips(rec.cpu().numpy(), o_rec)
+    assert flips == 0, flips                                        # learnt geometry: no top-k near-ties to flip
+    assert_psnr_parity(got, want, flips, pts.shape[0], "trained")   # 1e-3 dB, BASELINE's bound

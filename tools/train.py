@@ -58,6 +58,9 @@ def main():
     opt = torch.optim.Adam(params, lr=args.lr)
     aux_opt = torch.optim.Adam(aux_params, lr=args.aux_lr)
     red = par.GradBucketReducer(params)
+    # the bottleneck (.quantiles) parameters are averaged across ranks as well: they set the CDF tables update()
+    # builds, and every rank must end up with the same tables (rank 0 alone writes the checkpoint)
+    aux_red = par.GradBucketReducer(aux_params)
     qgen = Q_Map({"mode": "exponential", "lambda_A_max": 12800, "lambda_A_min": 100, "lambda_G_max": 1600, "lambda_G_min": 25})
     loss_fn = Loss(OURS_LOSS)
     t0 = time.time()
@@ -85,6 +88,7 @@ def main():
         opt.step()
         aux = model.aux_loss()
         aux.backward()
+        aux_red.finish()
         aux_opt.step()
         if rank == 0 and (step % args.log_every == 0 or step == 1):
             print(f"step {step:5d}  loss {float(total.detach()):9.3f}  " +
