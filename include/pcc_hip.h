@@ -16,8 +16,13 @@
  *     available from pcc_last_error() (thread-local).  No exceptions cross the ABI.
  *   - coordinates: int32 [N,4] rows (batch, x, y, z), |x|,|y|,|z| < 32767, batch < 32767.
  *   - features: fp32 row-major [N, C].  Neighbour tables: int32 [N_out, K], -1 = absent.
- *   - hash table = (keys uint64[cap], vals int32[cap]), cap a power of two from
+ *   - hash table = (keys uint64[cap], vals int32[cap], tensor_stride), cap a power of two from
  *     pcc_hash_capacity(); a table is immutable once built and may be read concurrently.
+ *     `tensor_stride` is the grid pitch of the coordinate set the table indexes (every coordinate a
+ *     multiple of it; 1 for arbitrary integer coordinates): the slot function keeps 8 grid steps
+ *     along z in one cache line, so build and every later probe must name the same value (any
+ *     value >= 1 is correct, the set's own stride is the fast one).  pcc_stride_map / pcc_children /
+ *     pcc_kernel_map derive it from their `ts` / `step` arguments.
  */
 #ifndef PCC_HIP_H
 #define PCC_HIP_H
@@ -53,13 +58,13 @@ int64_t pcc_hash_capacity(int64_t n);
 /* Insert rows 0..n-1; table value = row index.  Duplicate coordinates keep the smallest
  * row index and increment *dup_count (device int32, may be NULL). */
 int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
-                   int32_t* dup_count, void* stream);
+                   int32_t tensor_stride, int32_t* dup_count, void* stream);
 
 /* out_idx[i] = row of query i or -1.  (features_at_coordinates on on-grid integer queries:
  * model/transforms.py:96,124,262; model/blocks.py:37,50; model/entropy_models.py:326,364,401;
  * torch.isin of model/blocks.py:125.) */
-int pcc_hash_lookup(const uint64_t* keys, const int32_t* vals, int64_t cap, const int32_t* query,
-                    int64_t nq, int32_t* out_idx, void* stream);
+int pcc_hash_lookup(const uint64_t* keys, const int32_t* vals, int64_t cap, int32_t tensor_stride,
+                    const int32_t* query, int64_t nq, int32_t* out_idx, void* stream);
 
 /* Scratch (int32 elements) needed by pcc_stride_map / pcc_children / pcc_compact_* for m candidates. */
 int64_t pcc_scan_scratch_elems(int64_t m);
@@ -258,7 +263,7 @@ int pcc_octree_expand(const uint8_t* occupancy, const int64_t* level_counts, int
  * (Chebyshev shells searched: 0..max_radius) get nn_idx = nn_d2 = -1 and must be retried wider.
  * ------------------------------------------------------------------------------------- */
 int pcc_nn_search(const int32_t* query, int64_t nq, const uint64_t* keys, const int32_t* vals, int64_t cap,
-                  const double* target_rgb, int32_t max_radius, int32_t* nn_idx, int64_t* nn_d2,
+                  int32_t tensor_stride, const double* target_rgb, int32_t max_radius, int32_t* nn_idx, int64_t* nn_d2,
                   int32_t* tie_count, double* tie_rgb, void* stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -22,8 +22,8 @@ SIGNATURES = {
     "pcc_device_count": (c_int, []),
     "pcc_device_name": (c_int, [c_int, ctypes.c_char_p, c_int]),
     "pcc_hash_capacity": (c_i64, [c_i64]),
-    "pcc_hash_build": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_void_p]),
-    "pcc_hash_lookup": (c_int, [c_void_p, c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_void_p]),
+    "pcc_hash_build": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "pcc_hash_lookup": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),
     "pcc_scan_scratch_elems": (c_i64, [c_i64]),
     "pcc_stride_map": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_children": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -58,7 +58,7 @@ SIGNATURES = {
     "pcc_octree_scratch_bytes": (c_i64, [c_i64]),
     "pcc_octree_occupancy": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_octree_expand": (c_int, [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_i64, c_void_p, c_void_p, c_i64, c_void_p]),
-    "pcc_nn_search": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
+    "pcc_nn_search": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "pcc_eb_quantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_eb_dequantize": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),

@@ -56,15 +56,38 @@ __device__ __forceinline__ uint64_t hash_key(uint64_t k) {
     return k;
 }
 
-// Probe an open-addressing table (linear probing).  Returns row id or -1.
+// Slot function of the hashed-voxel table.  The 8 voxels of an aligned run along z (8 grid steps of the set's
+// tensor stride, `shift` = log2(stride)) share the hash of their run and differ in the low 3 slot bits, so they
+// sit in ONE 64-byte line of `keys` (and one 32-byte sector of `vals`): the 3 dz probes of a kernel offset
+// column, and the probes of neighbouring rows, hit the same lines instead of 27 random ones.  Probing advances
+// by 8 slots — each of the 8 lanes is an ordinary linear-probing table over runs, so dense runs do not lengthen
+// the unsuccessful probes the way slot-by-slot probing through a spatial block does.
+__device__ __forceinline__ uint64_t table_slot0(uint64_t key, uint64_t mask, int shift) {
+    const uint64_t z = key & 0xFFFFull;
+    const uint64_t run = (key & ~0xFFFFull) | (z >> (shift + 3));
+    const uint64_t h = hash_key(run);
+    // the run's lanes are rotated by 3 hash bits the bucket index does not use: a degenerate set (a plane of
+    // constant z, a wrong `shift`) still spreads evenly over the 8 lanes
+    return ((h << 3) | (((z >> shift) + (h >> 61)) & 7ull)) & mask;
+}
+constexpr uint64_t TABLE_PROBE_STEP = 8;
+
+__host__ __device__ __forceinline__ int grid_shift_of(int tensor_stride) {      // log2 for powers of two, else 0
+    int s = 0;
+    if (tensor_stride > 0 && (tensor_stride & (tensor_stride - 1)) == 0)
+        while ((1 << s) < tensor_stride) ++s;
+    return s;
+}
+
+// Probe the table.  Returns row id or -1.
 __device__ __forceinline__ int table_find(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                          uint64_t mask, uint64_t key) {
-    uint64_t slot = hash_key(key) & mask;
-    for (uint64_t probe = 0; probe <= mask; ++probe) {
+                                          uint64_t mask, int shift, uint64_t key) {
+    uint64_t slot = table_slot0(key, mask, shift);
+    for (uint64_t probe = 0; probe <= mask; probe += TABLE_PROBE_STEP) {
         const uint64_t k = keys[slot];
         if (k == key) return vals[slot];
         if (k == KEY_EMPTY) return -1;
-        slot = (slot + 1) & mask;
+        slot = (slot + TABLE_PROBE_STEP) & mask;
     }
     return -1;
 }

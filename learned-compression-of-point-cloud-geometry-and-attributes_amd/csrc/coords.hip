@@ -132,9 +132,9 @@ __global__ void table_clear(uint64_t* __restrict__ keys, int32_t* __restrict__ v
 }
 
 // claim (or find) the slot of `key`; returns slot index
-__device__ __forceinline__ uint64_t table_claim(uint64_t* keys, uint64_t mask, uint64_t key) {
-    uint64_t slot = hash_key(key) & mask;
-    for (uint64_t probe = 0; probe <= mask; ++probe) {
+__device__ __forceinline__ uint64_t table_claim(uint64_t* keys, uint64_t mask, int shift, uint64_t key) {
+    uint64_t slot = table_slot0(key, mask, shift);
+    for (uint64_t probe = 0; probe <= mask; probe += TABLE_PROBE_STEP) {
         uint64_t cur = keys[slot];
         if (cur == KEY_EMPTY) {
             cur = (uint64_t)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)KEY_EMPTY,
@@ -142,9 +142,9 @@ __device__ __forceinline__ uint64_t table_claim(uint64_t* keys, uint64_t mask, u
             if (cur == KEY_EMPTY) return slot;
         }
         if (cur == key) return slot;
-        slot = (slot + 1) & mask;
+        slot = (slot + TABLE_PROBE_STEP) & mask;
     }
-    return mask + 1;  // table full: cannot happen with cap >= 2 * candidates
+    return mask + 1;  // lane full: cannot happen with cap >= 2 * candidates spread over the 8 lanes by (z / stride) & 7
 }
 
 // Candidate generators ------------------------------------------------------------------------
@@ -186,13 +186,13 @@ struct GenChildren {  // ks=3: candidate i = (parent i / 27, offset i % 27); ks=
 
 template <class Gen>
 __global__ __launch_bounds__(256) void unique_insert(Gen gen, int64_t m, uint64_t* __restrict__ keys,
-                                                     int32_t* __restrict__ vals, uint64_t mask,
+                                                     int32_t* __restrict__ vals, uint64_t mask, int shift,
                                                      int32_t* __restrict__ slot_of) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     int b, x, y, z;
     gen.get(i, b, x, y, z);
-    const uint64_t slot = table_claim(keys, mask, pack_key(b, x, y, z));
+    const uint64_t slot = table_claim(keys, mask, shift, pack_key(b, x, y, z));
     slot_of[i] = (int32_t)slot;
     if (slot <= mask) atomicMin(&vals[slot], (int32_t)i);
 }
@@ -235,7 +235,7 @@ __global__ void table_decode_vals(int32_t* __restrict__ vals, int64_t cap) {
 }
 
 template <class Gen>
-static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* scratch,
+static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int64_t cap, int shift, int32_t* scratch,
                          int32_t* out_coords, int64_t* out_count, hipStream_t st) {
     PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "hash capacity %lld is not a power of two", (long long)cap);
     PCC_REQUIRE(cap >= 2 * m, "hash capacity %lld too small for %lld candidates", (long long)cap, (long long)m);
@@ -249,7 +249,7 @@ static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int6
     int32_t* flags = scratch + m;
     int32_t* block_sums = scratch + 2 * m;
     const unsigned nb = blocks_for(m, 256);
-    hipLaunchKernelGGL(unique_insert<Gen>, dim3(nb), dim3(256), 0, st, gen, m, keys, vals, (uint64_t)(cap - 1), slot_of);
+    hipLaunchKernelGGL(unique_insert<Gen>, dim3(nb), dim3(256), 0, st, gen, m, keys, vals, (uint64_t)(cap - 1), shift, slot_of);
     hipLaunchKernelGGL(unique_flag, dim3(nb), dim3(256), 0, st, m, vals, slot_of, flags);
     int rc = exclusive_scan(flags, m, flags, block_sums, out_count, st);
     if (rc) return rc;
@@ -262,41 +262,45 @@ static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int6
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void build_insert(const int32_t* __restrict__ coords, int64_t n,
                                                     uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
-                                                    uint64_t mask) {
+                                                    uint64_t mask, int shift) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
-    const uint64_t slot = table_claim(keys, mask, pack_key(c.x, c.y, c.z, c.w));
+    const uint64_t slot = table_claim(keys, mask, shift, pack_key(c.x, c.y, c.z, c.w));
     if (slot <= mask) atomicMin(&vals[slot], (int32_t)i);
 }
 
 __global__ __launch_bounds__(256) void build_count_dups(const int32_t* __restrict__ coords, int64_t n,
                                                         const uint64_t* __restrict__ keys,
-                                                        const int32_t* __restrict__ vals, uint64_t mask,
+                                                        const int32_t* __restrict__ vals, uint64_t mask, int shift,
                                                         int32_t* __restrict__ dup_count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
-    if (table_find(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w)) != (int32_t)i) atomicAdd(dup_count, 1);
+    if (table_find(keys, vals, mask, shift, pack_key(c.x, c.y, c.z, c.w)) != (int32_t)i) atomicAdd(dup_count, 1);
 }
 
 __global__ __launch_bounds__(256) void lookup_kernel(const uint64_t* __restrict__ keys,
-                                                     const int32_t* __restrict__ vals, uint64_t mask,
+                                                     const int32_t* __restrict__ vals, uint64_t mask, int shift,
                                                      const int32_t* __restrict__ query, int64_t nq,
                                                      int32_t* __restrict__ out_idx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nq) return;
     const int4 c = reinterpret_cast<const int4*>(query)[i];
-    out_idx[i] = table_find(keys, vals, mask, pack_key(c.x, c.y, c.z, c.w));
+    out_idx[i] = table_find(keys, vals, mask, shift, pack_key(c.x, c.y, c.z, c.w));
 }
 
-// One 256-thread block per group of 64 output rows: 64*K probes, coalesced nbr stores,
-// group mask reduced in LDS.
+// One 256-thread block per group of 64 output rows: 64*K probes, coalesced nbr stores, row masks reduced in LDS.
+// Lanes walk (row, offset) pairs offset-fastest, so the three dz probes of a (dx, dy) column sit in one wave
+// instruction and — the table keeps a z-run in one line (table_slot0) — are served by one line request.
+// Transposed maps (parent = c - d * step must lie on the parent grid of pitch 2 * step) skip the offsets whose
+// parity rules the parent out: 1 + (c mod 2 step != 0) candidates per axis instead of 3 (k = 3), 1 instead of 2
+// (k = 2) — 3.4 probes per row on average instead of 27.
 __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restrict__ out_coords, int64_t n_out,
                                                          const uint64_t* __restrict__ keys,
-                                                         const int32_t* __restrict__ vals, uint64_t mask, int ks,
-                                                         int K, int step, int32_t* __restrict__ nbr,
-                                                         uint32_t* __restrict__ row_mask,
+                                                         const int32_t* __restrict__ vals, uint64_t mask, int shift,
+                                                         int ks, int K, int step, int parent_pitch,
+                                                         int32_t* __restrict__ nbr, uint32_t* __restrict__ row_mask,
                                                          unsigned long long* __restrict__ pair_count) {
     __shared__ int4 rows[64];
     __shared__ unsigned rm[64];
@@ -305,8 +309,8 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
     if (threadIdx.x < 64) {
         const int64_t r = row0 + threadIdx.x;
         rows[threadIdx.x] = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
+        rm[threadIdx.x] = 0u;
     }
-    if (threadIdx.x < 64) rm[threadIdx.x] = 0u;
     if (threadIdx.x == 0) hits_s = 0u;
     __syncthreads();
     unsigned myhits = 0u;
@@ -318,7 +322,11 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
         int dx, dy, dz;
         kernel_offset(ks, k, dx, dy, dz);
         const int4 c = rows[lr];
-        const int idx = table_find(keys, vals, mask, pack_key(c.x, c.y + dx * step, c.z + dy * step, c.w + dz * step));
+        const int x = c.y + dx * step, y = c.z + dy * step, z = c.w + dz * step;
+        int idx = -1;
+        // parent_pitch > 0 (transposed): off-grid targets cannot exist in the parent set — no probe
+        const bool on_grid = parent_pitch <= 0 || (((x % parent_pitch) | (y % parent_pitch) | (z % parent_pitch)) == 0);
+        if (on_grid) idx = table_find(keys, vals, mask, shift, pack_key(c.x, x, y, z));
         nbr[r * K + k] = idx;
         if (idx >= 0) { atomicOr(&rm[lr], 1u << k); ++myhits; }
     }
@@ -447,30 +455,33 @@ int64_t pcc_hash_capacity(int64_t n) {
 
 int64_t pcc_scan_scratch_elems(int64_t m) { return 2 * m + (m + SCAN_TILE - 1) / SCAN_TILE + 16; }
 
-int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap, int32_t* dup_count,
-                   void* stream) {
+int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap, int32_t tensor_stride,
+                   int32_t* dup_count, void* stream) {
     hipStream_t st = as_stream(stream);
+    PCC_REQUIRE(tensor_stride >= 1, "pcc_hash_build: tensor stride must be >= 1");
+    const int shift = grid_shift_of(tensor_stride);
     PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0 && cap >= 2 * n, "pcc_hash_build: bad capacity %lld for n=%lld",
                 (long long)cap, (long long)n);
     hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap);
     if (dup_count) PCC_CHECK_HIP(hipMemsetAsync(dup_count, 0, sizeof(int32_t), st));
     if (n > 0) {
         hipLaunchKernelGGL(build_insert, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys, vals,
-                           (uint64_t)(cap - 1));
+                           (uint64_t)(cap - 1), shift);
         if (dup_count)
             hipLaunchKernelGGL(build_count_dups, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys, vals,
-                               (uint64_t)(cap - 1), dup_count);
+                               (uint64_t)(cap - 1), shift, dup_count);
     }
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
 
-int pcc_hash_lookup(const uint64_t* keys, const int32_t* vals, int64_t cap, const int32_t* query, int64_t nq,
-                    int32_t* out_idx, void* stream) {
+int pcc_hash_lookup(const uint64_t* keys, const int32_t* vals, int64_t cap, int32_t tensor_stride, const int32_t* query,
+                    int64_t nq, int32_t* out_idx, void* stream) {
     PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "pcc_hash_lookup: bad capacity");
+    PCC_REQUIRE(tensor_stride >= 1, "pcc_hash_lookup: tensor stride must be >= 1");
     if (nq <= 0) return PCC_OK;
     hipLaunchKernelGGL(lookup_kernel, dim3(blocks_for(nq, 256)), dim3(256), 0, as_stream(stream), keys, vals,
-                       (uint64_t)(cap - 1), query, nq, out_idx);
+                       (uint64_t)(cap - 1), grid_shift_of(tensor_stride), query, nq, out_idx);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
@@ -479,7 +490,7 @@ int pcc_stride_map(const int32_t* coords, int64_t n, int32_t ts, uint64_t* keys,
                    int32_t* scratch, int32_t* out_coords, int64_t* out_count, void* stream) {
     PCC_REQUIRE(ts >= 1, "pcc_stride_map: tensor stride must be >= 1");
     GenStride gen{coords, 2 * ts};
-    return unique_coords(gen, n, keys, vals, cap, scratch, out_coords, out_count, as_stream(stream));
+    return unique_coords(gen, n, keys, vals, cap, grid_shift_of(2 * ts), scratch, out_coords, out_count, as_stream(stream));
 }
 
 int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, uint64_t* keys, int32_t* vals,
@@ -488,7 +499,7 @@ int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, ui
     PCC_REQUIRE(ts >= 2 && (ts % 2) == 0, "pcc_children: tensor stride %d is not even", ts);
     const int K = ksize * ksize * ksize;
     GenChildren gen{coords, n, ksize, ts / 2};
-    return unique_coords(gen, n * K, keys, vals, cap, scratch, out_coords, out_count, as_stream(stream));
+    return unique_coords(gen, n * K, keys, vals, cap, grid_shift_of(ts / 2), scratch, out_coords, out_count, as_stream(stream));
 }
 
 int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals,
@@ -500,9 +511,12 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
     if (pair_count) PCC_CHECK_HIP(hipMemsetAsync(pair_count, 0, sizeof(int64_t), as_stream(stream)));
     if (n_out <= 0) return PCC_OK;
     const int K = ksize * ksize * ksize;
+    PCC_REQUIRE(step >= 1, "pcc_kernel_map: step must be >= 1");
+    // the input set's grid: pitch `step` for a (strided) convolution, 2 * step for a transposed one
+    const int in_stride = sign > 0 ? step : 2 * step;
     hipLaunchKernelGGL(kernel_map_kernel, dim3(blocks_for(n_out, 64)), dim3(256), 0, as_stream(stream), out_coords,
-                       n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), ksize, K, sign * step, nbr, row_mask,
-                       reinterpret_cast<unsigned long long*>(pair_count));
+                       n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), ksize, K, sign * step,
+                       sign > 0 ? 0 : 2 * step, nbr, row_mask, reinterpret_cast<unsigned long long*>(pair_count));
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -17,7 +17,7 @@ namespace pcc {
 
 __global__ __launch_bounds__(256) void nn_search_kernel(const int32_t* __restrict__ query, int64_t nq,
                                                         const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
-                                                        uint64_t mask, const double* __restrict__ target_rgb, int max_radius,
+                                                        uint64_t mask, int shift, const double* __restrict__ target_rgb, int max_radius,
                                                         int32_t* __restrict__ nn_idx, int64_t* __restrict__ nn_d2,
                                                         int32_t* __restrict__ tie_count, double* __restrict__ tie_rgb) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void nn_search_kernel(const int32_t* __restric
                     const int64_t d2 = (int64_t)dx * dx + (int64_t)dy * dy + (int64_t)dz * dz;
                     if (d2 > best) continue;
                     const uint64_t key = pack_key(b, x + dx, y + dy, z + dz);
-                    const int idx = table_find(keys, vals, mask, key);
+                    const int idx = table_find(keys, vals, mask, shift, key);
                     if (idx < 0) continue;
                     if (d2 < best) {
                         best = d2; best_key = key; best_idx = idx; ties = 0;
@@ -68,15 +68,16 @@ using namespace pcc;
 extern "C" {
 
 int pcc_nn_search(const int32_t* query, int64_t nq, const uint64_t* keys, const int32_t* vals, int64_t cap,
-                  const double* target_rgb, int32_t max_radius, int32_t* nn_idx, int64_t* nn_d2,
+                  int32_t tensor_stride, const double* target_rgb, int32_t max_radius, int32_t* nn_idx, int64_t* nn_d2,
                   int32_t* tie_count, double* tie_rgb, void* stream) {
     PCC_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0, "pcc_nn_search: table capacity must be a power of two");
     PCC_REQUIRE(max_radius >= 0 && max_radius <= 1024, "pcc_nn_search: max_radius out of range");
+    PCC_REQUIRE(tensor_stride >= 1, "pcc_nn_search: tensor stride must be >= 1");
     PCC_REQUIRE(nn_idx != nullptr && nn_d2 != nullptr, "pcc_nn_search: outputs required");
     PCC_REQUIRE(tie_rgb == nullptr || target_rgb != nullptr, "pcc_nn_search: tie colours need the target's colours");
     if (nq <= 0) return PCC_OK;
     hipLaunchKernelGGL(nn_search_kernel, dim3(blocks_for(nq, 256)), dim3(256), 0, as_stream(stream), query, nq, keys, vals, (uint64_t)cap - 1,
-                       target_rgb, max_radius, nn_idx, nn_d2, tie_count, tie_rgb);
+                       grid_shift_of(tensor_stride), target_rgb, max_radius, nn_idx, nn_d2, tie_count, tie_rgb);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

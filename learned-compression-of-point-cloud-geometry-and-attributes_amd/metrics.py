@@ -73,7 +73,7 @@ def nearest_neighbours(query_coords, target_map, target_rgb=None):
             o_d2 = torch.empty(m, dtype=torch.int64, device=dev)
             o_t = torch.empty(m, dtype=torch.int32, device=dev)
             o_s = None if rgb64 is None else torch.empty((m, 3), dtype=torch.float64, device=dev)
-        check(L.pcc_nn_search(ptr(q), q.shape[0], ptr(keys), ptr(vals), cap, ptr(rgb64), radius, ptr(o_idx), ptr(o_d2), ptr(o_t),
+        check(L.pcc_nn_search(ptr(q), q.shape[0], ptr(keys), ptr(vals), cap, target_map.stride, ptr(rgb64), radius, ptr(o_idx), ptr(o_d2), ptr(o_t),
                               ptr(o_s), _lib.stream()))
         if todo is not None:
             idx[todo], d2[todo], ties[todo] = o_idx, o_d2, o_t

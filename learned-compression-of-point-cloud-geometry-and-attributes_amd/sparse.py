@@ -72,7 +72,7 @@ class CoordMap:
             cap = L.pcc_hash_capacity(self.n)
             keys = torch.empty(cap, dtype=torch.int64, device=self.device)
             vals = torch.empty(cap, dtype=torch.int32, device=self.device)
-            check(L.pcc_hash_build(ptr(self.coords), self.n, ptr(keys), ptr(vals), cap, None, _lib.stream()))
+            check(L.pcc_hash_build(ptr(self.coords), self.n, ptr(keys), ptr(vals), cap, self.stride, None, _lib.stream()))
             self._table = (keys, vals, cap)
         return self._table
 
@@ -81,7 +81,7 @@ class CoordMap:
         keys, vals, cap = self.table()
         q = _as_int_coords(query)
         out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
-        check(_lib.lib().pcc_hash_lookup(ptr(keys), ptr(vals), cap, ptr(q), q.shape[0], ptr(out), _lib.stream()))
+        check(_lib.lib().pcc_hash_lookup(ptr(keys), ptr(vals), cap, self.stride, ptr(q), q.shape[0], ptr(out), _lib.stream()))
         return out
 
     # -- derived coordinate sets -------------------------------------------------------------

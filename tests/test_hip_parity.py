@@ -69,7 +69,7 @@ def test_hash_build_counts_duplicates(pcc):
     vals = torch.empty(cap, dtype=torch.int32, device=DEV)
     cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
     d = dev(dup)
-    check(L.pcc_hash_build(ptr(d), dup.shape[0], ptr(keys), ptr(vals), cap, ptr(cnt), stream()))
+    check(L.pcc_hash_build(ptr(d), dup.shape[0], ptr(keys), ptr(vals), cap, 1, ptr(cnt), stream()))
     assert int(cnt.item()) == 37
 
 
