@@ -9,6 +9,7 @@
 #include <stdio.h>
 
 #include "common.h"
+#include "sort.h"
 
 namespace pcc {
 
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_of_block_sums(int32_t* __rest
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const int32_t* __restrict__ flags, int64_t m,
                                                          const int32_t* __restrict__ block_offsets,
-                                                         int32_t* __restrict__ pos) {
+                                                         int32_t* __restrict__ pos, int inclusive) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
     int f[SCAN_ITEMS];
     int v = 0;
@@ -102,23 +103,31 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const int32_t* __restri
     int ex = block_exclusive_scan(v, &tot) + block_offsets[blockIdx.x];
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
-        if (base + i < m) pos[base + i] = ex;
+        if (base + i < m) pos[base + i] = inclusive ? ex + f[i] : ex;
         ex += f[i];
     }
 }
 
-// flags and pos may alias (in-place).  block_sums: ceil(m / SCAN_TILE) ints.
-static int exclusive_scan(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total,
-                          hipStream_t st) {
+int64_t scan_block_sums_elems(int64_t m) { return (m + SCAN_TILE - 1) / SCAN_TILE + 16; }
+
+// flags and pos may alias (in-place).  block_sums: scan_block_sums_elems(m) ints.
+int scan_flags(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total, int inclusive,
+               hipStream_t st) {
     const int64_t nb = (m + SCAN_TILE - 1) / SCAN_TILE;
     if (m <= 0) {
-        return hipMemsetAsync(total, 0, sizeof(int64_t), st) == hipSuccess ? PCC_OK : PCC_ERR_HIP;
+        if (total) PCC_CHECK_HIP(hipMemsetAsync(total, 0, sizeof(int64_t), st));
+        return PCC_OK;
     }
     hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums);
     hipLaunchKernelGGL(scan_of_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sums, nb, total);
-    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums, pos);
+    hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums, pos, inclusive);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
+}
+
+static int exclusive_scan(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total,
+                          hipStream_t st) {
+    return scan_flags(flags, m, pos, block_sums, total, 0, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -336,6 +345,77 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
     if (threadIdx.x == 0 && pair_count && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
 }
 
+// Kernel size 3 (every large map of the codec): one 576-thread block per 64 output rows.  Wave = (dx, dy) column
+// of the kernel, lane = output row: a thread probes the column's three dz targets — one hash per z-run (the three
+// share a run 3 times out of 4), the three first-slot loads issued together, then the three value loads — and the
+// 64 x 27 table tile is assembled in LDS and written out with full lines.  No runtime division anywhere (the
+// generic kernel below spends ~200 instructions per probe on e / K, k % ks and the 64-bit hash; this one ~50).
+template <bool POW2>
+__global__ __launch_bounds__(576) void kernel_map3_kernel(const int32_t* __restrict__ out_coords, int64_t n_out,
+                                                          const uint64_t* __restrict__ keys,
+                                                          const int32_t* __restrict__ vals, uint64_t mask, int shift,
+                                                          int step, int parent_pitch, int32_t* __restrict__ nbr,
+                                                          uint32_t* __restrict__ row_mask,
+                                                          unsigned long long* __restrict__ pair_count) {
+    __shared__ int32_t tile[64 * 27];
+    __shared__ unsigned rm[64];
+    const int lane = threadIdx.x & 63, col = threadIdx.x >> 6;       // col = (dx + 1) + 3 (dy + 1)
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    const int64_t r = row0 + lane;
+    if (threadIdx.x < 64) rm[threadIdx.x] = 0u;
+    __syncthreads();
+    int idx[3] = {-1, -1, -1};
+    if (r < n_out) {
+        const int4 c = reinterpret_cast<const int4*>(out_coords)[r];
+        const int dx = col % 3 - 1, dy = col / 3 - 1;
+        const int x = c.y + dx * step, y = c.z + dy * step;
+        // transposed maps: a parent exists only on the grid of pitch parent_pitch (= 2 |step|)
+        auto off_grid = [&](int v) { return parent_pitch > 0 && (POW2 ? (v & (parent_pitch - 1)) != 0 : (v % parent_pitch) != 0); };
+        if (!off_grid(x) && !off_grid(y)) {
+            uint64_t key[3], slot[3], q[3];
+            bool live[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int z = c.w + (j - 1) * step;
+                live[j] = !off_grid(z);
+                key[j] = pack_key(c.x, x, y, z);
+                slot[j] = table_slot0(key[j], mask, shift);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) q[j] = live[j] ? keys[slot[j]] : KEY_EMPTY;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                // continue along the lane only on a collision (rare at load <= 1/2)
+                for (uint64_t probe = 0; q[j] != key[j] && q[j] != KEY_EMPTY && probe <= mask; probe += TABLE_PROBE_STEP) {
+                    slot[j] = (slot[j] + TABLE_PROBE_STEP) & mask;
+                    q[j] = keys[slot[j]];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) idx[j] = (q[j] == key[j]) ? vals[slot[j]] : -1;
+        }
+    }
+    unsigned bits = 0u;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        tile[lane * 27 + 9 * j + col] = idx[j];                       // stride 27 words: conflict-free
+        bits |= (idx[j] >= 0) ? (1u << (9 * j + col)) : 0u;
+    }
+    if (bits) atomicOr(&rm[lane], bits);
+    __syncthreads();
+    const int rows = (int)((n_out - row0 < 64) ? (n_out - row0) : 64);
+    int32_t* dst = nbr + row0 * 27;
+    for (int e = threadIdx.x; e < rows * 27; e += 576) dst[e] = tile[e];
+    if (threadIdx.x < 64) {
+        const unsigned m = (threadIdx.x < rows) ? rm[threadIdx.x] : 0u;
+        if (row_mask && threadIdx.x < rows) row_mask[row0 + threadIdx.x] = m;
+        int hits = __popc(m);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
+        if (threadIdx.x == 0 && pair_count && hits) atomicAdd(pair_count, (unsigned long long)hits);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, int c,
                                                           const int32_t* __restrict__ idx, int64_t n,
@@ -514,9 +594,22 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
     PCC_REQUIRE(step >= 1, "pcc_kernel_map: step must be >= 1");
     // the input set's grid: pitch `step` for a (strided) convolution, 2 * step for a transposed one
     const int in_stride = sign > 0 ? step : 2 * step;
-    hipLaunchKernelGGL(kernel_map_kernel, dim3(blocks_for(n_out, 64)), dim3(256), 0, as_stream(stream), out_coords,
-                       n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), ksize, K, sign * step,
-                       sign > 0 ? 0 : 2 * step, nbr, row_mask, reinterpret_cast<unsigned long long*>(pair_count));
+    const int pitch = sign > 0 ? 0 : 2 * step;
+    if (ksize == 3) {
+        const bool pow2 = pitch == 0 || (pitch & (pitch - 1)) == 0;
+        if (pow2)
+            hipLaunchKernelGGL(kernel_map3_kernel<true>, dim3(blocks_for(n_out, 64)), dim3(576), 0, as_stream(stream), out_coords, n_out,
+                               in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask,
+                               reinterpret_cast<unsigned long long*>(pair_count));
+        else
+            hipLaunchKernelGGL(kernel_map3_kernel<false>, dim3(blocks_for(n_out, 64)), dim3(576), 0, as_stream(stream), out_coords, n_out,
+                               in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask,
+                               reinterpret_cast<unsigned long long*>(pair_count));
+    } else {
+        hipLaunchKernelGGL(kernel_map_kernel, dim3(blocks_for(n_out, 64)), dim3(256), 0, as_stream(stream), out_coords,
+                           n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), ksize, K, sign * step,
+                           pitch, nbr, row_mask, reinterpret_cast<unsigned long long*>(pair_count));
+    }
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -10,13 +10,10 @@
 // bytes back to coordinates (decode).  The bytes then go through the same host range coder as the
 // latents (rans_host.cpp).  All of it is HBM/latency-bound integer work: 8 B key + 1 B output per
 // node and level.
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
+#include "sort.h"
 
 namespace pcc {
-
-static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 __device__ __forceinline__ uint64_t spread3(uint32_t v) {       // bit b -> bit 3 b (21 bits)
     uint64_t x = v & 0x1fffffu;
@@ -112,11 +109,9 @@ __global__ __launch_bounds__(256) void octree_coords_kernel(const uint64_t* __re
     coords[4 * i + 3] = (int)compact3(k) * stride + oz;
 }
 
-static size_t cub_temp_bytes(int64_t n) {
-    size_t a = 0, b = 0;
-    const int m = (int)(n > 0 ? n : 1);
-    (void)hipcub::DeviceRadixSort::SortKeys(nullptr, a, (const uint64_t*)nullptr, (uint64_t*)nullptr, m);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, b, (const int32_t*)nullptr, (int32_t*)nullptr, m);
+// scratch behind the fixed arrays: radix-sort counters, or the block sums of a scan (never both at once)
+static int64_t octree_temp_bytes(int64_t n) {
+    const int64_t a = radix_sort_counter_bytes(n), b = align256(scan_block_sums_elems(n) * 4);
     return a > b ? a : b;
 }
 
@@ -128,7 +123,7 @@ extern "C" {
 
 int64_t pcc_octree_scratch_bytes(int64_t n) {
     if (n < 1) n = 1;
-    return align256((int64_t)cub_temp_bytes(n)) + 2 * align256(n * 8) + 3 * align256(n * 4) + 256;
+    return octree_temp_bytes(n) + 2 * align256(n * 8) + 3 * align256(n * 4) + 256;
 }
 
 int pcc_octree_occupancy(const int32_t* coords, int64_t n, int32_t stride, const int32_t* origin, int32_t depth,
@@ -143,25 +138,30 @@ int pcc_octree_occupancy(const int32_t* coords, int64_t n, int32_t stride, const
     int32_t* head = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
     int32_t* rank = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
     uint32_t* words = reinterpret_cast<uint32_t*>(p); p += align256(n * 4);
-    size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
+    int32_t* temp = reinterpret_cast<int32_t*>(p);
     const unsigned nb = blocks_for(n, 256);
     PCC_CHECK_HIP(hipMemsetAsync(level_counts, 0, (size_t)(depth + 2) * sizeof(int32_t), st));
     hipLaunchKernelGGL(octree_keys_kernel, dim3(nb), dim3(256), 0, st, coords, n, stride, origin[0], origin[1], origin[2], depth,
                        keys_in, level_counts + depth + 1);
-    if (depth > 0)
-        PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortKeys(p, temp, keys_in, keys, (int)n, 0, 3 * depth, st));
-    else
+    if (depth > 0) {
+        // keys only matter; the values (head / rank double as the value ping-pong) are overwritten below
+        const int rc = radix_sort_pairs_u64(keys_in, keys, head, rank, true, n, 0, 3 * depth, temp, st);
+        if (rc) return rc;
+        if (!radix_sort_result_in_b(0, 3 * depth))
+            PCC_CHECK_HIP(hipMemcpyAsync(keys, keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    } else {
         PCC_CHECK_HIP(hipMemcpyAsync(keys, keys_in, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+    }
     for (int L = 0; L < depth; ++L) {
         hipLaunchKernelGGL(octree_heads_kernel, dim3(nb), dim3(256), 0, st, keys, n, 3 * (depth - L), head);
-        PCC_CHECK_HIP(hipcub::DeviceScan::InclusiveSum(p, temp, head, rank, (int)n, st));
+        { const int rc = scan_flags(head, n, rank, temp, nullptr, 1, st); if (rc) return rc; }
         PCC_CHECK_HIP(hipMemsetAsync(words, 0, (size_t)n * 4, st));
         hipLaunchKernelGGL(octree_or_kernel, dim3(nb), dim3(256), 0, st, keys, rank, n, 3 * (depth - L - 1), words, level_counts + L);
         hipLaunchKernelGGL(octree_pack_kernel, dim3(nb), dim3(256), 0, st, words, level_counts + L, n, occupancy + (int64_t)L * n);
     }
     // number of distinct leaves (== n unless the input holds duplicates)
     hipLaunchKernelGGL(octree_heads_kernel, dim3(nb), dim3(256), 0, st, keys, n, 0, head);
-    PCC_CHECK_HIP(hipcub::DeviceScan::InclusiveSum(p, temp, head, rank, (int)n, st));
+    { const int rc = scan_flags(head, n, rank, temp, nullptr, 1, st); if (rc) return rc; }
     hipLaunchKernelGGL(octree_last_kernel, dim3(1), dim3(256), 0, st, rank, n, level_counts + depth);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
@@ -182,7 +182,7 @@ int pcc_octree_expand(const uint8_t* occupancy, const int64_t* level_counts, int
     uint64_t* b = reinterpret_cast<uint64_t*>(p); p += align256(n_points * 8);
     int32_t* pc = reinterpret_cast<int32_t*>(p); p += align256(n_points * 4);
     int32_t* incl = reinterpret_cast<int32_t*>(p); p += 2 * align256(n_points * 4);
-    size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
+    int32_t* temp = reinterpret_cast<int32_t*>(p);
     PCC_CHECK_HIP(hipMemsetAsync(a, 0, 8, st));     // the root: prefix 0
     int64_t off = 0;
     for (int L = 0; L < depth; ++L) {
@@ -190,7 +190,7 @@ int pcc_octree_expand(const uint8_t* occupancy, const int64_t* level_counts, int
         const int64_t next = (L + 1 < depth) ? level_counts[L + 1] : n_points;
         const unsigned nb = blocks_for(nl, 256);
         hipLaunchKernelGGL(octree_popc_kernel, dim3(nb), dim3(256), 0, st, occupancy + off, nl, pc);
-        PCC_CHECK_HIP(hipcub::DeviceScan::InclusiveSum(p, temp, pc, incl, (int)nl, st));
+        { const int rc = scan_flags(pc, nl, incl, temp, nullptr, 1, st); if (rc) return rc; }
         hipLaunchKernelGGL(octree_children_kernel, dim3(nb), dim3(256), 0, st, a, occupancy + off, incl, nl, next, b);
         uint64_t* t = a; a = b; b = t;
         off += nl;

@@ -8,9 +8,8 @@
 // thread arrival order.  No host synchronisation: all passes are enqueued; a batch that has
 // resolved early turns the remaining passes into no-ops through its `done` word.
 // HBM-bound wavefront-level integer work, no dense contraction.
-#include <hipcub/hipcub.hpp>
-
 #include "common.h"
+#include "sort.h"
 
 namespace pcc {
 
@@ -70,11 +69,18 @@ __global__ __launch_bounds__(256) void topk_hist(const float* __restrict__ logit
     __shared__ int lh[TK_LDS_BATCHES * 256];
     const bool use_lds = nbatch <= TK_LDS_BATCHES;
     if (use_lds) {
+        // every item resolved (distinct logits resolve within the four passes over the fp32 key): the remaining
+        // passes are enqueued all the same (no host sync) and return here without touching the rows
+        bool all_done = true;
+        for (int b = 0; b < nbatch; ++b) all_done &= state[(int64_t)b * TK_STRIDE + 1] != 0;
+        if (all_done) return;
         for (int i = threadIdx.x; i < nbatch * 256; i += 256) lh[i] = 0;
         __syncthreads();
     }
+    // one batch item and a pass over the logit bytes: the coordinates (item index, tie-break key) are not needed
+    const bool logit_only = nbatch == 1 && pass < 4;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        const int4 c = logit_only ? make_int4(0, 0, 0, 0) : reinterpret_cast<const int4*>(coords)[i];
         const int b = c.x;
         if (b < 0 || b >= nbatch) continue;
         const int32_t* st = state + (int64_t)b * TK_STRIDE;
@@ -142,61 +148,66 @@ __global__ __launch_bounds__(256) void topk_write_mask(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void coords_to_keys(const int32_t* __restrict__ coords, int64_t n,
-                                                      uint64_t* __restrict__ keys, int32_t* __restrict__ iota) {
+                                                      uint64_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     keys[i] = pack_key(c.x, c.y, c.z, c.w);
-    iota[i] = (int32_t)i;
 }
-
-static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 // ---- execution order of a kernel map's output rows -------------------------------------------
-// key = (spatial block id << 27) | 27-bit neighbour mask; rows with equal masks become adjacent
-// so that 32-row MFMA tiles execute (almost) only offsets every row of the tile has.
-__global__ __launch_bounds__(256) void order_keys_kernel(const uint32_t* __restrict__ row_mask,
-                                                         const int32_t* __restrict__ coords, int64_t n,
-                                                         int block_log2, int ts, uint64_t* __restrict__ keys,
-                                                         int32_t* __restrict__ iota) {
+// key = (27 - popcount) << 27 | 27-bit neighbour mask (32 bits; with spatial blocks the block id goes on top:
+// 64 bits).  Rows with equal masks become adjacent so that 32-row MFMA tiles execute (almost) only offsets
+// every row of the tile has; the heaviest rows come first: tiles are dispatched in key order, so the expensive
+// ones start early and the tail of a launch consists of cheap tiles.
+__global__ __launch_bounds__(256) void order_keys32_kernel(const uint32_t* __restrict__ row_mask, int64_t n,
+                                                           uint32_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    // heaviest rows first (27 - popcount in the bits above the mask): tiles are dispatched in key
-    // order, so the expensive ones start early and the tail of a launch consists of cheap tiles
     const uint32_t m = row_mask[i] & 0x7FFFFFFu;
-    uint64_t key = ((uint64_t)(27 - __popc(m)) << 27) | m;
-    if (block_log2 >= 0) {
-        const int4 c = reinterpret_cast<const int4*>(coords)[i];
-        const uint64_t bx = (uint64_t)(((c.y / ts) + 512) >> block_log2) & 0x3FF;
-        const uint64_t by = (uint64_t)(((c.z / ts) + 512) >> block_log2) & 0x3FF;
-        const uint64_t bz = (uint64_t)(((c.w / ts) + 512) >> block_log2) & 0x3FF;
-        key |= ((((uint64_t)(c.x & 0x3) << 30) | (bx << 20) | (by << 10) | bz) << 32);
-    }
-    keys[i] = key;
-    iota[i] = (int32_t)i;
+    keys[i] = ((uint32_t)(27 - __popc(m)) << 27) | m;
 }
 
-// one wave per 32 sorted rows?  simpler: one thread per (sorted row, offset) for the table gather,
-// group masks reduced with a wave-level OR over each aligned 32-lane half.
+__global__ __launch_bounds__(256) void order_keys64_kernel(const uint32_t* __restrict__ row_mask,
+                                                           const int32_t* __restrict__ coords, int64_t n,
+                                                           int block_log2, int ts, uint64_t* __restrict__ keys) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = row_mask[i] & 0x7FFFFFFu;
+    uint64_t key = ((uint64_t)(27 - __popc(m)) << 27) | m;
+    const int4 c = reinterpret_cast<const int4*>(coords)[i];
+    const uint64_t bx = (uint64_t)(((c.y / ts) + 512) >> block_log2) & 0x3FF;
+    const uint64_t by = (uint64_t)(((c.z / ts) + 512) >> block_log2) & 0x3FF;
+    const uint64_t bz = (uint64_t)(((c.w / ts) + 512) >> block_log2) & 0x3FF;
+    key |= ((((uint64_t)(c.x & 0x3) << 30) | (bx << 20) | (by << 10) | bz) << 32);
+    keys[i] = key;
+}
+
+// Permuted neighbour table + one OR-mask per 32 positions.  A block owns 256 consecutive positions: their source
+// rows are staged in LDS, the masks of a 32-position group are OR-reduced inside its half-wave, and the table rows
+// (K ints each, contiguous in the source) are copied with the destination fully coalesced.
 __global__ __launch_bounds__(256) void order_apply_kernel(const int32_t* __restrict__ order,
                                                           const uint32_t* __restrict__ row_mask,
                                                           const int32_t* __restrict__ nbr, int64_t n, int K,
                                                           int32_t* __restrict__ nbr_sorted,
                                                           uint32_t* __restrict__ group_mask32) {
-    // part 1: group masks (threads 0..n-1 of the grid, one per sorted row)
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    uint32_t m = (i < n) ? row_mask[order[i]] : 0u;
+    __shared__ int32_t src_row[256];
+    const int64_t r0 = (int64_t)blockIdx.x * 256;
+    const int64_t i = r0 + threadIdx.x;
+    const int32_t src = (i < n) ? order[i] : 0;
+    src_row[threadIdx.x] = src;
+    uint32_t m = (i < n) ? row_mask[src] : 0u;
 #pragma unroll
     for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
     if (i < n && (threadIdx.x & 31) == 0) group_mask32[i >> 5] = m;
-    // part 2: permuted neighbour table, 256 rows per block, coalesced on the destination
-    const int64_t r0 = (int64_t)blockIdx.x * 256;
-    const int64_t rows = (n - r0 < 256) ? (n - r0) : 256;
-    const int64_t total = rows * K;
-    for (int64_t e = threadIdx.x; e < total; e += 256) {
-        const int64_t lr = e / K;
-        const int k = (int)(e - lr * K);
-        nbr_sorted[(r0 + lr) * K + k] = nbr[(int64_t)order[r0 + lr] * K + k];
+    __syncthreads();
+    const int rows = (int)((n - r0 < 256) ? (n - r0) : 256);
+    const int total = rows * K;
+    int32_t* dst = nbr_sorted + r0 * K;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int lr = e / K;
+        const int k = e - lr * K;
+        dst[e] = nbr[(int64_t)src_row[lr] * K + k];
     }
 }
 
@@ -236,18 +247,32 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     PCC_REQUIRE(n < (1ll << 31), "pcc_order_rows_by_mask: too many rows");
     PCC_REQUIRE(K >= 1 && K <= 27, "pcc_order_rows_by_mask: K out of range");
     PCC_REQUIRE(block_log2 < 0 || coords != nullptr, "pcc_order_rows_by_mask: block ordering needs coordinates");
+    PCC_REQUIRE(block_log2 <= 10, "pcc_order_rows_by_mask: block_log2 out of range");
     PCC_REQUIRE(tensor_stride >= 1, "pcc_order_rows_by_mask: bad tensor stride");
     PCC_REQUIRE(scratch_bytes >= pcc_sort_scratch_bytes(n), "pcc_order_rows_by_mask: scratch too small");
     hipStream_t st = as_stream(stream);
     char* p = reinterpret_cast<char*>(scratch);
-    uint64_t* keys_in = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
-    uint64_t* keys_out = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
-    int32_t* iota = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
-    size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
-    hipLaunchKernelGGL(order_keys_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, coords, n, block_log2,
-                       tensor_stride, keys_in, iota);
-    const int end_bit = block_log2 >= 0 ? 64 : 32;
-    PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(p, temp, keys_in, keys_out, iota, order, (int)n, 0, end_bit, st));
+    char* keys_a = p; p += align256(n * 8);
+    char* keys_b = p; p += align256(n * 8);
+    int32_t* vals_x = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
+    void* counters = p;
+    const int begin = 0, end = block_log2 >= 0 ? 64 : 32;
+    // the sorted values must land in `order`: they end in the b-side when the pass count is odd
+    const bool in_b = radix_sort_result_in_b(begin, end);
+    int32_t* va = in_b ? vals_x : order;
+    int32_t* vb = in_b ? order : vals_x;
+    int rc;
+    if (block_log2 < 0) {
+        hipLaunchKernelGGL(order_keys32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, n, reinterpret_cast<uint32_t*>(keys_a));
+        rc = radix_sort_pairs_u32(reinterpret_cast<uint32_t*>(keys_a), reinterpret_cast<uint32_t*>(keys_b), va, vb, true, n, begin, end,
+                                  counters, st);
+    } else {
+        hipLaunchKernelGGL(order_keys64_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, coords, n, block_log2, tensor_stride,
+                           reinterpret_cast<uint64_t*>(keys_a));
+        rc = radix_sort_pairs_u64(reinterpret_cast<uint64_t*>(keys_a), reinterpret_cast<uint64_t*>(keys_b), va, vb, true, n, begin, end,
+                                  counters, st);
+    }
+    if (rc) return rc;
     hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
                        nbr_sorted, group_mask32);
     PCC_LAUNCH_CHECK();
@@ -255,10 +280,8 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
 }
 
 int64_t pcc_sort_scratch_bytes(int64_t n) {
-    size_t temp = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, temp, (const uint64_t*)nullptr, (uint64_t*)nullptr,
-                                       (const int32_t*)nullptr, (int32_t*)nullptr, (int)(n > 0 ? n : 1));
-    return align256((int64_t)temp) + 2 * align256(n * 8) + align256(n * 4) + 256;
+    if (n < 1) n = 1;
+    return 2 * align256(n * 8) + align256(n * 4) + radix_sort_counter_bytes(n) + 256;
 }
 
 int pcc_sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* scratch, int64_t scratch_bytes, void* stream) {
@@ -267,13 +290,13 @@ int pcc_sort_coords(const int32_t* coords, int64_t n, int32_t* perm, void* scrat
     PCC_REQUIRE(scratch_bytes >= pcc_sort_scratch_bytes(n), "pcc_sort_coords: scratch too small");
     hipStream_t st = as_stream(stream);
     char* p = reinterpret_cast<char*>(scratch);
-    uint64_t* keys_in = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
-    uint64_t* keys_out = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
-    int32_t* iota = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
-    size_t temp = (size_t)(scratch_bytes - (p - reinterpret_cast<char*>(scratch)));
-    hipLaunchKernelGGL(coords_to_keys, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys_in, iota);
-    PCC_CHECK_HIP(hipcub::DeviceRadixSort::SortPairs(p, temp, keys_in, keys_out, iota, perm, (int)n, 0, 64, st));
-    return PCC_OK;
+    uint64_t* keys_a = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
+    uint64_t* keys_b = reinterpret_cast<uint64_t*>(p); p += align256(n * 8);
+    int32_t* vals_x = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
+    void* counters = p;
+    hipLaunchKernelGGL(coords_to_keys, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys_a);
+    const bool in_b = radix_sort_result_in_b(0, 64);
+    return radix_sort_pairs_u64(keys_a, keys_b, in_b ? vals_x : perm, in_b ? perm : vals_x, true, n, 0, 64, counters, st);
 }
 
 }  // extern "C"

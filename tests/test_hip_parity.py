@@ -392,6 +392,57 @@ def test_sort_permutation(pcc):
     assert (perm == oc.sort_order(c)).all()
 
 
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 4097, 98304, 98305, 300_001])
+def test_canonical_sort_all_sizes(pcc, n):
+    """the hand-written radix sort behind utils.sort_tensor / sort_points (utils.py:155-204): the single-workgroup
+    shape (n <= 98,304) and the count / scan / scatter shape above it, ragged tails, negative coordinates, several
+    batch items; the permutation must equal the oracle's exact lexicographic (b, x, y, z) order"""
+    rng = np.random.default_rng(n)
+    side = max(4, int(round((4 * n) ** (1 / 3))) + 2)
+    flat = rng.choice(side ** 3 * 3, size=n, replace=False)          # distinct (b, x, y, z)
+    b, rem = flat // side ** 3, flat % side ** 3
+    c = np.stack([b, rem // side ** 2 - side // 2, (rem // side) % side - 3, rem % side], axis=1).astype(np.int32)
+    perm = pcc.CoordMap(dev(c), 1).sort_permutation().cpu().numpy()
+    assert (perm == oc.sort_order(c)).all()
+
+
+@pytest.mark.parametrize("n,K", [(5, 27), (257, 27), (70_001, 8), (98_500, 27), (400_003, 27)])
+def test_mask_order_is_the_stable_sort_of_the_keys(pcc, n, K):
+    """pcc_order_rows_by_mask on synthetic masks (few distinct values -> long runs of equal keys, the real
+    distribution): `order` must be THE stable ascending sort of (27 - popcount) << 27 | mask — ranks come from
+    ballots and per-wave counters, never from atomics, so equal keys keep their row order — with the permuted
+    table and the 32-position OR-masks consistent with it"""
+    from pcc_amd._lib import ptr, check, stream
+    L = pcc.lib()
+    rng = np.random.default_rng(n + K)
+    palette = rng.integers(1, 1 << K, size=37, dtype=np.int64)
+    mask = palette[rng.integers(0, 37, size=n)]
+    mask[rng.integers(0, n, size=max(1, n // 50))] = rng.integers(0, 1 << K, size=max(1, n // 50))
+    nbr = np.where((mask[:, None] >> np.arange(K)) & 1, rng.integers(0, n, size=(n, K)), -1).astype(np.int32)
+    d_mask, d_nbr = dev(mask.astype(np.uint32).view(np.int32)), dev(nbr)
+    order = torch.empty(n, dtype=torch.int32, device=DEV)
+    nbr_s = torch.empty_like(d_nbr)
+    gm = torch.empty((n + 31) // 32, dtype=torch.int32, device=DEV)
+    nbytes = L.pcc_order_scratch_bytes(n)
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    check(L.pcc_order_rows_by_mask(ptr(d_mask), None, n, -1, 1, ptr(d_nbr), K, ptr(order), ptr(nbr_s), ptr(gm), ptr(scratch), nbytes,
+                                   stream()))
+    pc = np.array([bin(int(v) & 0x7FFFFFF).count("1") for v in palette])
+    popc = np.zeros(n, np.int64)
+    for v, p_ in zip(palette, pc):
+        popc[mask == v] = p_
+    odd = ~np.isin(mask, palette)
+    popc[odd] = [bin(int(v)).count("1") for v in mask[odd]]
+    key = ((27 - popc) << 27) | mask
+    want = np.argsort(key, kind="stable")
+    got = order.cpu().numpy()
+    assert (got == want).all()
+    assert (nbr_s.cpu().numpy() == nbr[want]).all()
+    g = gm.cpu().numpy().view(np.uint32).astype(np.int64)
+    sm = np.concatenate([mask[want], np.zeros((-n) % 32, np.int64)]).reshape(-1, 32)
+    assert (g == np.bitwise_or.reduce(sm, axis=1)).all()
+
+
 def test_count_per_batch(pcc):
     c = shell_coords(pcc, batch=3, seed=1)
     assert pcc.CoordMap(dev(c), 1).count_per_batch() == oc.count_per_batch(c)
