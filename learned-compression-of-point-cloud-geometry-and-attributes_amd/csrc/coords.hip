@@ -7,6 +7,7 @@
 // candidate index, so outputs are bit-reproducible).
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "common.h"
 #include "sort.h"
@@ -345,11 +346,59 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
     if (threadIdx.x == 0 && pair_count && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
 }
 
-// Kernel size 3 (every large map of the codec): one 576-thread block per 64 output rows.  Wave = (dx, dy) column
-// of the kernel, lane = output row: a thread probes the column's three dz targets — one hash per z-run (the three
-// share a run 3 times out of 4), the three first-slot loads issued together, then the three value loads — and the
-// 64 x 27 table tile is assembled in LDS and written out with full lines.  No runtime division anywhere (the
-// generic kernel below spends ~200 instructions per probe on e / K, k % ks and the 64-bit hash; this one ~50).
+// Kernel size 3 (every large map of the codec), same lane mapping as the generic kernel below — (row, offset) pairs
+// offset-fastest — with everything the generic kernel computes per probe hoisted out: K = 27 is a compile-time
+// constant (e / 27 is a multiply), the 27 offsets come from a table in LDS, and the parity test of transposed maps
+// is a mask.  The generic kernel spends ~200 instructions per probe on e / K, k % ks and runtime-pitch modulos.
+template <bool POW2>
+__global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __restrict__ out_coords, int64_t n_out,
+                                                           const uint64_t* __restrict__ keys,
+                                                           const int32_t* __restrict__ vals, uint64_t mask, int shift,
+                                                           int step, int parent_pitch, int32_t* __restrict__ nbr,
+                                                           uint32_t* __restrict__ row_mask,
+                                                           unsigned long long* __restrict__ pair_count) {
+    __shared__ int4 rows[64];
+    __shared__ int4 offs[27];
+    __shared__ unsigned rm[64];
+    __shared__ unsigned hits_s;
+    const int64_t row0 = (int64_t)blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const int64_t r = row0 + threadIdx.x;
+        rows[threadIdx.x] = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
+        rm[threadIdx.x] = 0u;
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) {
+        const int k = threadIdx.x - 64;
+        offs[k] = make_int4((k % 3 - 1) * step, ((k / 3) % 3 - 1) * step, (k / 9 - 1) * step, 0);
+    }
+    if (threadIdx.x == 0) hits_s = 0u;
+    __syncthreads();
+    const int nrows = (int)((n_out - row0 < 64) ? (n_out - row0) : 64);
+    const int total = nrows * 27;
+    unsigned myhits = 0u;
+    auto off_grid = [&](int v) { return POW2 ? (v & (parent_pitch - 1)) != 0 : (v % parent_pitch) != 0; };
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int lr = e / 27, k = e - lr * 27;
+        const int4 c = rows[lr];
+        const int4 o = offs[k];
+        const int x = c.y + o.x, y = c.z + o.y, z = c.w + o.z;
+        int idx = -1;
+        if (parent_pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z)))
+            idx = table_find(keys, vals, mask, shift, pack_key(c.x, x, y, z));
+        nbr[row0 * 27 + e] = idx;
+        if (idx >= 0) { atomicOr(&rm[lr], 1u << k); ++myhits; }
+    }
+    if (myhits) atomicAdd(&hits_s, myhits);
+    __syncthreads();
+    if (row_mask && threadIdx.x < nrows) row_mask[row0 + threadIdx.x] = rm[threadIdx.x];
+    if (threadIdx.x == 0 && pair_count && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
+}
+
+// Variant with wave = (dx, dy) column, lane = output row (one 576-thread block per 64 rows): a thread probes its
+// column's three dz targets with the three first-slot loads in flight together and the table tile is assembled in
+// LDS.  Measured SLOWER than the offset-fastest mapping on MI355X (5.16 M-row candidate set: 2.0 ms against
+// 1.35 ms): a wave instruction here touches 64 different lines, the offset-fastest one ~25 — the three dz lanes
+// of a column and the 27 lanes of a row coalesce.  Kept for A/B runs (PCC_KMAP_VARIANT=column).
 template <bool POW2>
 __global__ __launch_bounds__(576) void kernel_map3_kernel(const int32_t* __restrict__ out_coords, int64_t n_out,
                                                           const uint64_t* __restrict__ keys,
@@ -595,20 +644,30 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
     // the input set's grid: pitch `step` for a (strided) convolution, 2 * step for a transposed one
     const int in_stride = sign > 0 ? step : 2 * step;
     const int pitch = sign > 0 ? 0 : 2 * step;
-    if (ksize == 3) {
-        const bool pow2 = pitch == 0 || (pitch & (pitch - 1)) == 0;
-        if (pow2)
-            hipLaunchKernelGGL(kernel_map3_kernel<true>, dim3(blocks_for(n_out, 64)), dim3(576), 0, as_stream(stream), out_coords, n_out,
-                               in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask,
-                               reinterpret_cast<unsigned long long*>(pair_count));
-        else
-            hipLaunchKernelGGL(kernel_map3_kernel<false>, dim3(blocks_for(n_out, 64)), dim3(576), 0, as_stream(stream), out_coords, n_out,
-                               in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask,
-                               reinterpret_cast<unsigned long long*>(pair_count));
+    static int variant = -1;      // PCC_KMAP_VARIANT=generic|column: A/B switches (tools/kmap_bench.py); default = offset-fastest, K = 27
+    if (variant < 0) {
+        const char* e = getenv("PCC_KMAP_VARIANT");
+        variant = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 'c' ? 2 : 0));
+    }
+    const bool pow2 = pitch == 0 || (pitch & (pitch - 1)) == 0;
+    unsigned long long* pc = reinterpret_cast<unsigned long long*>(pair_count);
+    const uint64_t tmask = (uint64_t)(in_cap - 1);
+    const int tshift = grid_shift_of(in_stride);
+    const unsigned nb = blocks_for(n_out, 64);
+    hipStream_t st = as_stream(stream);
+    if (ksize == 3 && variant == 0) {
+        if (pow2) hipLaunchKernelGGL(kernel_map27_kernel<true>, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
+                                     sign * step, pitch, nbr, row_mask, pc);
+        else hipLaunchKernelGGL(kernel_map27_kernel<false>, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
+                                sign * step, pitch, nbr, row_mask, pc);
+    } else if (ksize == 3 && variant == 2) {
+        if (pow2) hipLaunchKernelGGL(kernel_map3_kernel<true>, dim3(nb), dim3(576), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
+                                     sign * step, pitch, nbr, row_mask, pc);
+        else hipLaunchKernelGGL(kernel_map3_kernel<false>, dim3(nb), dim3(576), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
+                                sign * step, pitch, nbr, row_mask, pc);
     } else {
-        hipLaunchKernelGGL(kernel_map_kernel, dim3(blocks_for(n_out, 64)), dim3(256), 0, as_stream(stream), out_coords,
-                           n_out, in_keys, in_vals, (uint64_t)(in_cap - 1), grid_shift_of(in_stride), ksize, K, sign * step,
-                           pitch, nbr, row_mask, reinterpret_cast<unsigned long long*>(pair_count));
+        hipLaunchKernelGGL(kernel_map_kernel, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift, ksize, K,
+                           sign * step, pitch, nbr, row_mask, pc);
     }
     PCC_LAUNCH_CHECK();
     return PCC_OK;

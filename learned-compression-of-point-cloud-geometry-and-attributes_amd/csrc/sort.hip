@@ -12,23 +12,25 @@
 // group's lowest lane.  Input order is (wave chunk, round, lane), so ranks are stable by construction and the
 // result does not depend on arrival order: no atomics decide a position.
 //
-// Two shapes:
-//   n <= RS_SMALL_N   one 1024-thread workgroup runs all passes (count sweep, scan in LDS, scatter sweep per
-//                     pass, ping-ponging between the two buffers): ONE launch for the 19 k / 72 k-row sets,
-//                     where a multi-kernel sort is nothing but launch latency;
-//   larger            per pass: count kernel (per-workgroup digit histograms, 8192 keys per workgroup) ->
-//                     one-workgroup scan of the 256 x workgroups counters -> scatter kernel (keys of the
-//                     workgroup held in registers between its count and its scatter sweep).
+// Three shapes (measured on MI355X; what bounds a small sort is launch count and load latency, not bytes):
+//   n <= 16 K         ONE launch: a 1024-thread workgroup runs all passes; a wave's chunk of the keys (<= 16 rounds of
+//                     64) is loaded into registers once per pass, so the count sweep and the scatter sweep pay the
+//                     global-load latency once instead of once per round;
+//   n <= 512 K        per pass two launches: per-workgroup digit histograms (2048 keys per workgroup), then the
+//                     scatter kernel, which sums the histograms of the workgroups in front of it itself (<= 256 of them);
+//   larger            per pass three launches: histograms (8192 keys per workgroup), one scan workgroup per digit
+//                     over that digit's row of counters, scatter.
 #include "sort.h"
 
 namespace pcc {
 
 constexpr int RS_SMALL_THREADS = 1024;
 constexpr int RS_SMALL_WAVES = RS_SMALL_THREADS / 64;
-constexpr int64_t RS_SMALL_N = 98304;
-constexpr int RS_ITEMS = 32;                    // keys per lane in the multi-workgroup kernels
-constexpr int RS_WAVE_KEYS = 64 * RS_ITEMS;     // 2048: a wave's contiguous chunk
-constexpr int RS_WG_KEYS = 4 * RS_WAVE_KEYS;    // 8192 keys per 256-thread workgroup
+constexpr int RS_SMALL_ROUNDS = 16;                                       // rounds of 64 keys per wave, held in registers
+constexpr int64_t RS_SMALL_N = (int64_t)RS_SMALL_WAVES * 64 * RS_SMALL_ROUNDS;   // 16384
+constexpr int RS_MID_ITEMS = 8;                   // keys per lane: 2048-key workgroups, self-prefixed scatter
+constexpr int RS_MID_MAX_UNITS = 256;             // n <= 524,288
+constexpr int RS_BIG_ITEMS = 32;                  // 8192-key workgroups, row-scan kernel between count and scatter
 
 // lanes of this wave that are active and hold the same 8-bit digit as the calling lane
 __device__ __forceinline__ uint64_t match_digit(unsigned d, bool active) {
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
     __shared__ int tot[256];
     __shared__ int wsum[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int chunk = ((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64 * 64;
+    const int chunk = ((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64 * 64;      // <= 64 * RS_SMALL_ROUNDS
     const int lo = w * chunk < n ? w * chunk : n;
     const int hi = lo + chunk < n ? lo + chunk : n;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -69,11 +71,22 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
     for (int p = 0; p < passes; ++p) {
         const int shift = begin_bit + 8 * p;
         const unsigned dmask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
+        // the wave's chunk in registers: one batch of loads per pass
+        K key[RS_SMALL_ROUNDS];
+        int32_t val[RS_SMALL_ROUNDS];
+#pragma unroll
+        for (int j = 0; j < RS_SMALL_ROUNDS; ++j) {
+            const int i = lo + j * 64 + lane;
+            key[j] = (i < hi) ? src[i] : (K)0;
+            val[j] = (i < hi) ? ((iota && p == 0) ? i : vs[i]) : 0;
+        }
         for (int i = t; i < RS_SMALL_WAVES * 256; i += RS_SMALL_THREADS) (&cnt[0][0])[i] = 0;
         __syncthreads();
-        for (int i = lo + lane; i < hi; i += 64) atomicAdd(&cnt[w][(unsigned)(src[i] >> shift) & dmask], 1);
+#pragma unroll
+        for (int j = 0; j < RS_SMALL_ROUNDS; ++j)
+            if (lo + j * 64 + lane < hi) atomicAdd(&cnt[w][(unsigned)(key[j] >> shift) & dmask], 1);
         __syncthreads();
-        // digit d: chunk bases (exclusive over the waves, input order) and the digit's total
+        // digit t: chunk bases (exclusive over the waves, input order) and the digit's total
         int v = 0;
         if (t < 256) {
             int run = 0;
@@ -94,19 +107,19 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
             tot[t] = base + inc - v;
         }
         __syncthreads();
-        for (int i0 = lo; i0 < hi; i0 += 64) {
-            const int i = i0 + lane;
+#pragma unroll
+        for (int j = 0; j < RS_SMALL_ROUNDS; ++j) {
+            const int i = lo + j * 64 + lane;
             const bool active = i < hi;
-            const K key = active ? src[i] : (K)0;
-            const unsigned d = (unsigned)(key >> shift) & dmask;
+            const unsigned d = (unsigned)(key[j] >> shift) & dmask;
             const uint64_t same = match_digit(d, active);
             const int below = __popcll(same & lt);
             int base = 0;
             if (active) {
                 base = cnt[w][d];
                 const int pos = tot[d] + base + below;
-                dst[pos] = key;
-                vd[pos] = (iota && p == 0) ? i : vs[i];
+                dst[pos] = key[j];
+                vd[pos] = val[j];
             }
             __builtin_amdgcn_wave_barrier();          // every lane has read its counter before a leader advances it
             if (active && below == 0) cnt[w][d] = base + __popcll(same);
@@ -118,37 +131,42 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
     }
 }
 
-// counts[d * nunits + u] = number of keys of workgroup u with digit d
-template <class K>
+// counts[d * nunits + u] = number of keys of workgroup u (256 * ITEMS consecutive keys) with digit d
+template <class K, int ITEMS>
 __global__ __launch_bounds__(256) void radix_count_kernel(const K* __restrict__ keys, int64_t n, int shift, unsigned dmask,
                                                           int64_t nunits, int32_t* __restrict__ counts) {
     __shared__ int cnt[256];
     cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_WG_KEYS;
-#pragma unroll 8
-    for (int j = 0; j < RS_ITEMS; ++j) {
+    const int64_t base = (int64_t)blockIdx.x * (256 * ITEMS);
+    K key[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
         const int64_t i = base + (int64_t)j * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&cnt[(unsigned)(keys[i] >> shift) & dmask], 1);
+        key[j] = (i < n) ? keys[i] : (K)0;
     }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (base + (int64_t)j * 256 + threadIdx.x < n) atomicAdd(&cnt[(unsigned)(key[j] >> shift) & dmask], 1);
     __syncthreads();
     counts[(int64_t)threadIdx.x * nunits + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// in-place exclusive scan of m ints by one workgroup (m = 256 x workgroups of the sort: a few 100 k at most)
-__global__ __launch_bounds__(1024) void radix_scan_kernel(int32_t* __restrict__ a, int64_t m) {
-    __shared__ int wsum[16];
+// one workgroup per digit: exclusive scan of the digit's row of `nunits` counters in place, row sum -> totals[digit]
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t* __restrict__ counts, int64_t nunits, int32_t* __restrict__ totals) {
+    __shared__ int wsum[4];
     __shared__ int carry_s;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    int32_t* row = counts + (int64_t)blockIdx.x * nunits;
     if (t == 0) carry_s = 0;
     __syncthreads();
-    for (int64_t base = 0; base < m; base += 4096) {
+    for (int64_t base = 0; base < nunits; base += 1024) {
         const int64_t i = base + 4 * (int64_t)t;
         int f[4];
         int v = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            f[j] = (i + j < m) ? a[i + j] : 0;
+            f[j] = (i + j < nunits) ? row[i + j] : 0;
             v += f[j];
         }
         const int inc = wave_inclusive_scan_i32(v, lane);
@@ -159,35 +177,63 @@ __global__ __launch_bounds__(1024) void radix_scan_kernel(int32_t* __restrict__ 
         int ex = pre + inc - v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (i + j < m) a[i + j] = ex;
+            if (i + j < nunits) row[i + j] = ex;
             ex += f[j];
         }
         __syncthreads();
-        if (t == 1023) carry_s = pre + inc;
+        if (t == 255) carry_s = pre + inc;
         __syncthreads();
     }
+    if (t == 0) totals[blockIdx.x] = carry_s;
 }
 
-template <class K>
+// SELF_PREFIX: `counts` holds the raw histograms; thread d sums its digit's row in front of this workgroup and over all
+// workgroups itself (nunits <= RS_MID_MAX_UNITS).  Otherwise `counts` is row-scanned and `totals` holds the row sums.
+template <class K, int ITEMS, bool SELF_PREFIX>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict__ src, K* __restrict__ dst, const int32_t* __restrict__ vs,
                                                             int32_t* __restrict__ vd, int iota, int64_t n, int shift, unsigned dmask,
-                                                            int64_t nunits, const int32_t* __restrict__ scanned) {
+                                                            int64_t nunits, const int32_t* __restrict__ counts,
+                                                            const int32_t* __restrict__ totals) {
     __shared__ int cnt[4][256];
+    __shared__ int wsum[4];
+    constexpr int WAVE_KEYS = 64 * ITEMS;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     for (int i = t; i < 4 * 256; i += 256) (&cnt[0][0])[i] = 0;
-    __syncthreads();
-    const int64_t wbase = (int64_t)blockIdx.x * RS_WG_KEYS + (int64_t)w * RS_WAVE_KEYS;
-    K key[RS_ITEMS];
+    const int64_t wbase = (int64_t)blockIdx.x * (4 * WAVE_KEYS) + (int64_t)w * WAVE_KEYS;
+    K key[ITEMS];
+    int32_t val[ITEMS];
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         const int64_t i = wbase + j * 64 + lane;
         key[j] = (i < n) ? src[i] : (K)0;
-        if (i < n) atomicAdd(&cnt[w][(unsigned)(key[j] >> shift) & dmask], 1);
+        val[j] = (i < n) ? (iota ? (int32_t)i : vs[i]) : 0;
+    }
+    // digit t: rows in front of this workgroup and the digit's total
+    int pre, total;
+    if (SELF_PREFIX) {
+        const int32_t* row = counts + (int64_t)t * nunits;
+        pre = 0;
+        total = 0;
+        for (int64_t u = 0; u < nunits; ++u) {
+            const int c = row[u];
+            total += c;
+            pre += (u < (int64_t)blockIdx.x) ? c : 0;
+        }
+    } else {
+        pre = counts[(int64_t)t * nunits + blockIdx.x];
+        total = totals[t];
     }
     __syncthreads();
-    {   // digit t: global base of the workgroup, then of each of its waves (input order)
-        int run = scanned[(int64_t)t * nunits + blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j)
+        if (wbase + j * 64 + lane < n) atomicAdd(&cnt[w][(unsigned)(key[j] >> shift) & dmask], 1);
+    const int inc = wave_inclusive_scan_i32(total, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    {   // global base of digit t for this workgroup, then for each of its waves (input order)
+        int run = pre + inc - total;
+        for (int ww = 0; ww < w; ++ww) run += wsum[ww];
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) {
             const int c = cnt[ww][t];
@@ -197,9 +243,8 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < RS_ITEMS; ++j) {
-        const int64_t i = wbase + j * 64 + lane;
-        const bool active = i < n;
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool active = wbase + j * 64 + lane < n;
         const unsigned d = (unsigned)(key[j] >> shift) & dmask;
         const uint64_t same = match_digit(d, active);
         const int below = __popcll(same & lt);
@@ -208,7 +253,7 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
             base = cnt[w][d];
             const int64_t pos = (int64_t)base + below;
             dst[pos] = key[j];
-            vd[pos] = iota ? (int32_t)i : vs[i];
+            vd[pos] = val[j];
         }
         __builtin_amdgcn_wave_barrier();
         if (active && below == 0) cnt[w][d] = base + __popcll(same);
@@ -219,8 +264,9 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
 int radix_sort_passes(int begin_bit, int end_bit) { return end_bit > begin_bit ? (end_bit - begin_bit + 7) / 8 : 0; }
 
 int64_t radix_sort_counter_bytes(int64_t n) {
-    const int64_t nunits = (n + RS_WG_KEYS - 1) / RS_WG_KEYS;
-    return align256(256 * (nunits > 0 ? nunits : 1) * 4);
+    const int64_t mid = (n + 256 * RS_MID_ITEMS - 1) / (256 * RS_MID_ITEMS), big = (n + 256 * RS_BIG_ITEMS - 1) / (256 * RS_BIG_ITEMS);
+    const int64_t nunits = mid <= RS_MID_MAX_UNITS ? mid : big;
+    return align256(256 * (nunits > 0 ? nunits : 1) * 4) + 1024;       // counters + 256 row totals
 }
 
 template <class K>
@@ -236,8 +282,11 @@ static int radix_sort_pairs(K* ka, K* kb, int32_t* va, int32_t* vb, bool iota, i
         PCC_LAUNCH_CHECK();
         return PCC_OK;
     }
-    const int64_t nunits = (n + RS_WG_KEYS - 1) / RS_WG_KEYS;
+    const int64_t mid_units = (n + 256 * RS_MID_ITEMS - 1) / (256 * RS_MID_ITEMS);
+    const bool mid = mid_units <= RS_MID_MAX_UNITS;
+    const int64_t nunits = mid ? mid_units : (n + 256 * RS_BIG_ITEMS - 1) / (256 * RS_BIG_ITEMS);
     int32_t* counts = reinterpret_cast<int32_t*>(counters);
+    int32_t* totals = counts + align256(256 * nunits * 4) / 4;
     K* src = ka;
     K* dst = kb;
     int32_t* vs = va;
@@ -245,10 +294,17 @@ static int radix_sort_pairs(K* ka, K* kb, int32_t* va, int32_t* vb, bool iota, i
     for (int p = 0; p < passes; ++p) {
         const int shift = begin_bit + 8 * p;
         const unsigned dmask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
-        hipLaunchKernelGGL(radix_count_kernel<K>, dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
-        hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, counts, 256 * nunits);
-        hipLaunchKernelGGL(radix_scatter_kernel<K>, dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, (iota && p == 0) ? 1 : 0, n, shift,
-                           dmask, nunits, counts);
+        const int io = (iota && p == 0) ? 1 : 0;
+        if (mid) {
+            hipLaunchKernelGGL((radix_count_kernel<K, RS_MID_ITEMS>), dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
+            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_MID_ITEMS, true>), dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, io, n,
+                               shift, dmask, nunits, counts, totals);
+        } else {
+            hipLaunchKernelGGL((radix_count_kernel<K, RS_BIG_ITEMS>), dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, st, counts, nunits, totals);
+            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_BIG_ITEMS, false>), dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, io, n,
+                               shift, dmask, nunits, counts, totals);
+        }
         K* tk = src; src = dst; dst = tk;
         int32_t* tv = vs; vs = vd; vd = tv;
     }

@@ -392,10 +392,10 @@ def test_sort_permutation(pcc):
     assert (perm == oc.sort_order(c)).all()
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 4097, 98304, 98305, 300_001])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 1023, 4097, 16384, 16385, 300_001, 524_288, 524_289])
 def test_canonical_sort_all_sizes(pcc, n):
     """the hand-written radix sort behind utils.sort_tensor / sort_points (utils.py:155-204): the single-workgroup
-    shape (n <= 98,304) and the count / scan / scatter shape above it, ragged tails, negative coordinates, several
+    shape (n <= 16,384), the count / self-prefixed scatter shape (n <= 524,288) and the count / row-scan / scatter shape above it, ragged tails, negative coordinates, several
     batch items; the permutation must equal the oracle's exact lexicographic (b, x, y, z) order"""
     rng = np.random.default_rng(n)
     side = max(4, int(round((4 * n) ** (1 / 3))) + 2)
@@ -406,7 +406,7 @@ def test_canonical_sort_all_sizes(pcc, n):
     assert (perm == oc.sort_order(c)).all()
 
 
-@pytest.mark.parametrize("n,K", [(5, 27), (257, 27), (70_001, 8), (98_500, 27), (400_003, 27)])
+@pytest.mark.parametrize("n,K", [(5, 27), (257, 27), (16_385, 8), (98_500, 27), (600_003, 27)])
 def test_mask_order_is_the_stable_sort_of_the_keys(pcc, n, K):
     """pcc_order_rows_by_mask on synthetic masks (few distinct values -> long runs of equal keys, the real
     distribution): `order` must be THE stable ascending sort of (27 - popcount) << 27 | mask — ranks come from
