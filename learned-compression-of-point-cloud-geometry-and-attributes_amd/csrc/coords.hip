@@ -214,33 +214,22 @@ __global__ __launch_bounds__(256) void unique_flag(int64_t m, const int32_t* __r
     flags[i] = (vals[slot_of[i]] == (int32_t)i) ? 1 : 0;
 }
 
+// incl = inclusive scan of the winner flags: candidate i won its slot iff the scan steps at i, and its output row
+// is incl[i] - 1.  The winner test reads the scan, never `vals`, so the slot can be rewritten to the row id at once.
 template <class Gen>
 __global__ __launch_bounds__(256) void unique_finalize(Gen gen, int64_t m, int32_t* __restrict__ vals,
                                                        const int32_t* __restrict__ slot_of,
-                                                       const int32_t* __restrict__ pos,
+                                                       const int32_t* __restrict__ incl,
                                                        int32_t* __restrict__ out_coords) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    const int32_t slot = slot_of[i];
-    // winner test must not read vals after another winner rewrote it: winners own distinct slots,
-    // and a loser's candidate index can never equal a winner's compacted position *and* lose,
-    // so test against the flag implied by the scan instead: pos[i+1] - pos[i] is unavailable for the
-    // last element, hence recompute from vals only for slots not yet finalised (vals >= 0 always).
-    // To stay race-free we use a negative encoding: finalised slots hold -(row+1).
-    const int32_t v = vals[slot];
-    if (v == (int32_t)i) {
-        const int32_t row = pos[i];
+    const int32_t cur = incl[i], prev = i ? incl[i - 1] : 0;
+    if (cur != prev) {
+        const int32_t row = cur - 1;
         int b, x, y, z;
         gen.get(i, b, x, y, z);
         reinterpret_cast<int4*>(out_coords)[row] = make_int4(b, x, y, z);
-        vals[slot] = -(row + 1);
-    }
-}
-
-__global__ void table_decode_vals(int32_t* __restrict__ vals, int64_t cap) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t v = vals[i];
-        if (v < 0) vals[i] = -v - 1;
+        vals[slot_of[i]] = row;
     }
 }
 
@@ -261,10 +250,9 @@ static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int6
     const unsigned nb = blocks_for(m, 256);
     hipLaunchKernelGGL(unique_insert<Gen>, dim3(nb), dim3(256), 0, st, gen, m, keys, vals, (uint64_t)(cap - 1), shift, slot_of);
     hipLaunchKernelGGL(unique_flag, dim3(nb), dim3(256), 0, st, m, vals, slot_of, flags);
-    int rc = exclusive_scan(flags, m, flags, block_sums, out_count, st);
+    int rc = scan_flags(flags, m, flags, block_sums, out_count, 1, st);
     if (rc) return rc;
     hipLaunchKernelGGL(unique_finalize<Gen>, dim3(nb), dim3(256), 0, st, gen, m, vals, slot_of, flags, out_coords);
-    hipLaunchKernelGGL(table_decode_vals, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, vals, cap);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
@@ -343,7 +331,7 @@ __global__ __launch_bounds__(256) void kernel_map_kernel(const int32_t* __restri
     if (myhits) atomicAdd(&hits_s, myhits);
     __syncthreads();
     if (row_mask && threadIdx.x < 64 && row0 + threadIdx.x < n_out) row_mask[row0 + threadIdx.x] = rm[threadIdx.x];
-    if (threadIdx.x == 0 && pair_count && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
+    if (threadIdx.x == 0 && pair_count && !row_mask && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
 }
 
 // Kernel size 3 (every large map of the codec), same lane mapping as the generic kernel below — (row, offset) pairs
@@ -391,7 +379,7 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     if (myhits) atomicAdd(&hits_s, myhits);
     __syncthreads();
     if (row_mask && threadIdx.x < nrows) row_mask[row0 + threadIdx.x] = rm[threadIdx.x];
-    if (threadIdx.x == 0 && pair_count && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
+    if (threadIdx.x == 0 && pair_count && !row_mask && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
 }
 
 // Variant with wave = (dx, dy) column, lane = output row (one 576-thread block per 64 rows): a thread probes its
@@ -461,7 +449,25 @@ __global__ __launch_bounds__(576) void kernel_map3_kernel(const int32_t* __restr
         int hits = __popc(m);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
-        if (threadIdx.x == 0 && pair_count && hits) atomicAdd(pair_count, (unsigned long long)hits);
+        if (threadIdx.x == 0 && pair_count && !row_mask && hits) atomicAdd(pair_count, (unsigned long long)hits);
+    }
+}
+
+// pairs = sum of popcount(row_mask).  A separate grid-stride reduction with a few hundred workgroups: one atomic per
+// workgroup of the MAP kernel on the single counter serialises at the L2 — 80 k same-address atomics were 1.0 of the
+// 1.35 ms of the 5.16 M-row map (a transposed map with an eighth of the probes took the same time).
+__global__ __launch_bounds__(256) void pair_count_kernel(const uint32_t* __restrict__ row_mask, int64_t n,
+                                                         unsigned long long* __restrict__ pair_count) {
+    __shared__ unsigned long long ws[4];
+    unsigned long long v = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v += __popc(row_mask[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t = ws[0] + ws[1] + ws[2] + ws[3];
+        if (t) atomicAdd(pair_count, t);
     }
 }
 
@@ -669,6 +675,8 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
         hipLaunchKernelGGL(kernel_map_kernel, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift, ksize, K,
                            sign * step, pitch, nbr, row_mask, pc);
     }
+    if (pair_count && row_mask)
+        hipLaunchKernelGGL(pair_count_kernel, dim3(blocks_for(n_out, 256 * 16, 512)), dim3(256), 0, st, row_mask, n_out, pc);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
