@@ -63,12 +63,17 @@ __device__ __forceinline__ uint64_t hash_key(uint64_t k) {
 // by 8 slots — each of the 8 lanes is an ordinary linear-probing table over runs, so dense runs do not lengthen
 // the unsuccessful probes the way slot-by-slot probing through a spatial block does.
 __device__ __forceinline__ uint64_t table_slot0(uint64_t key, uint64_t mask, int shift) {
-    const uint64_t z = key & 0xFFFFull;
-    const uint64_t run = (key & ~0xFFFFull) | (z >> (shift + 3));
-    const uint64_t h = hash_key(run);
-    // the run's lanes are rotated by 3 hash bits the bucket index does not use: a degenerate set (a plane of
-    // constant z, a wrong `shift`) still spreads evenly over the 8 lanes
-    return ((h << 3) | (((z >> shift) + (h >> 61)) & 7ull)) & mask;
+    const uint32_t z = (uint32_t)key & 0xFFFFu;
+    // 32-bit mix of the run (b, x | y, z-run): the probe kernels are bound by VALU issue as much as by memory, and a
+    // 64-bit splitmix is ~55 issue slots on CDNA (four quarter-rate 32-bit multiplies per 64-bit product) against ~25 here
+    const uint32_t lo = ((uint32_t)key & 0xFFFF0000u) | (z >> (shift + 3)), hi = (uint32_t)(key >> 32);
+    uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du;
+    h ^= h >> 12; h *= 0x297A2D39u;
+    h ^= h >> 15;
+    // the run's lanes are rotated by 3 hash bits the bucket index does not use (cap <= 2^31 slots = 2^28 buckets): a
+    // degenerate set (a plane of constant z, a wrong `shift`) still spreads evenly over the 8 lanes
+    return (((uint64_t)h << 3) | (((z >> shift) + (h >> 29)) & 7u)) & mask;
 }
 constexpr uint64_t TABLE_PROBE_STEP = 8;
 
