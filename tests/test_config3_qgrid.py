@@ -62,8 +62,10 @@ def test_q_grid_vs_oracle(pcc, model, oracle_codec, frame):
         qc, qf = syn.uniform_qmap(pts[:, :3], q_g, q_a)
         bpp, o_bpp, m, om, flips = _compare(pcc, model, oracle_codec, pts, qc, qf, (frame, q_g, q_a))
         rates.append((bpp, o_bpp))
-    # the four operating points are four different codings, on the GPU exactly as in the oracle
-    assert len({round(r[0], 6) for r in rates}) == 4 and len({round(r[1], 6) for r in rates}) == 4
+    # which operating points coincide (the seeded FiLM heads start near (beta, gamma) = (1, 0): on a small frame a
+    # change of q may flip no symbol at all) is itself a result the GPU must share with the oracle
+    same = lambda vals: [[abs(a - b) < 1e-9 for b in vals] for a in vals]
+    assert same([r[0] for r in rates]) == same([r[1] for r in rates]), rates
 
 
 def test_non_uniform_quality_maps_vs_oracle(pcc, model, oracle_codec):
