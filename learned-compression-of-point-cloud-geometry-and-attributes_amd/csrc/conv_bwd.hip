@@ -561,8 +561,11 @@ static inline int wgrad_splits(int64_t n_out) {            // at least ~48 row g
 // quad kernel (four offsets per workgroup): 64-channel-class blocks of a 27-offset kernel; PCC_WGRAD_QUAD=0 keeps the
 // one-offset kernel for A/B runs
 static inline bool wgrad_quad(int cin, int cout, int K) {
+    // opt-in (PCC_WGRAD_QUAD=1): measured on MI355X it moves 25 % fewer bytes than the one-offset kernel and takes the
+    // same time (850 k-row shell 64 -> 64: 49.8 vs 57.2 TFLOP/s; 265 k rows: 54.9 vs 48.3) — the loop is bound by the
+    // round trips between its barriers, not by gather bytes
     static int on = -1;
-    if (on < 0) { const char* e = getenv("PCC_WGRAD_QUAD"); on = (e && e[0] == '0') ? 0 : 1; }
+    if (on < 0) { const char* e = getenv("PCC_WGRAD_QUAD"); on = (e && e[0] == '1') ? 1 : 0; }
     return on && wgrad_rowsplit(cin, cout) && K == 27;
 }
 static inline int wgrad_partials(int cin, int cout, int split, int K) {

@@ -24,7 +24,11 @@ assert rows, "no launches of at least %.1f ms" % min_ms
 t = sum(a for a, _ in rows)
 c = sum(b for _, b in rows)
 try:
+    if os.environ.get("PCC_PROFILE_COMMIT"):          # the commit the GPU passes ran at, when HEAD has moved on since
+        raise KeyError
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+except KeyError:
+    commit = os.environ["PCC_PROFILE_COMMIT"]
 except Exception:
     commit = None
 from bench import kernel_source_sha256

@@ -28,9 +28,13 @@ assert n > 0, "no matching dispatches"
 fb = sum(fetch.values()) / len(fetch) * 1024 * 2
 wb = sum(write.values()) / len(write) * 1024
 try:
+    if os.environ.get("PCC_PROFILE_COMMIT"):          # the commit the GPU passes ran at, when HEAD has moved on since
+        raise KeyError
     commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "learned-compression-of-point-cloud-geometry-and-attributes_amd/csrc"], text=True).strip())
     commit += "+uncommitted csrc changes" if dirty else ""
+except KeyError:
+    commit = os.environ["PCC_PROFILE_COMMIT"]
 except Exception:
     commit = None
 from bench import kernel_source_sha256
