@@ -290,6 +290,16 @@ int pcc_eb_likelihood(const float* z_hat, int64_t n, int32_t c, const float* eb_
 int pcc_gc_encode_prep(const float* y, const float* params, int64_t n, int32_t c,
                        const float* scale_table, int32_t levels, int32_t* symbols,
                        int32_t* indexes, void* stream);
+/* The same preparation with the planes the host coder reads directly, already in stream order: output column j
+ * takes row perm[j] (perm may be NULL = identity; the reference sorts its tensors canonically before coding,
+ * utils.py:155-180, model/entropy_models.py:357-372), symbols as int16 [c,n] (may be NULL: indexes only, the
+ * decoder's case), indexes as uint8 [c,n] (levels <= 256).  *overflow (device int32, required with symbols) is
+ * set to 1 when a symbol does not fit int16 — the caller then uses pcc_gc_encode_prep. */
+int pcc_gc_encode_prep_packed(const float* y, const float* params, int64_t n, int32_t c,
+                              const float* scale_table, int32_t levels, const int32_t* perm,
+                              int16_t* symbols, uint8_t* indexes, int32_t* overflow, void* stream);
+int pcc_gc_dequantize_i16(const int16_t* symbols, const float* params, int64_t n, int32_t c,
+                          float* y_hat, void* stream);
 /* y_hat[n,c] = symbols[c,n] + mean[n,c]  (GaussianConditional.decompress/dequantize). */
 int pcc_gc_dequantize(const int32_t* symbols, const float* params, int64_t n, int32_t c, float* y_hat,
                       void* stream);
@@ -309,6 +319,15 @@ int64_t pcc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* inde
 int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
                                  const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
                                  const int32_t* offsets, int32_t* out_symbols);
+/* The same coder on the packed planes of pcc_gc_encode_prep_packed (int16 symbols, uint8 indexes): identical
+ * bytes.  The decoder sets *narrowed (host int32, required) to 1 when a decoded symbol does not fit int16 —
+ * out_symbols is then unusable and the caller repeats the decode with pcc_rans_decode_with_indexes. */
+int64_t pcc_rans_encode_with_indexes_i16u8(const int16_t* symbols, const uint8_t* indexes, int64_t n,
+                                           const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                           const int32_t* offsets, uint8_t* out, int64_t out_cap);
+int pcc_rans_decode_with_indexes_u8i16(const uint8_t* data, int64_t nbytes, const uint8_t* indexes, int64_t n,
+                                       const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                       const int32_t* offsets, int16_t* out_symbols, int32_t* narrowed);
 /* cdf has n+1 entries. */
 int pcc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf);
 

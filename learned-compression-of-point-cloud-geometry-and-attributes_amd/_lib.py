@@ -65,6 +65,10 @@ SIGNATURES = {
     "pcc_eb_likelihood": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_gc_encode_prep": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_gc_dequantize": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "pcc_gc_encode_prep_packed": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_gc_dequantize_i16": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
+    "pcc_rans_encode_with_indexes_i16u8": (c_i64, [c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64]),
+    "pcc_rans_decode_with_indexes_u8i16": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_gc_forward": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_rans_encode_with_indexes": (c_i64, [c_void_p, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p, c_i64]),
     "pcc_rans_decode_with_indexes": (c_int, [c_void_p, c_i64, c_void_p, c_i64, c_void_p, c_i32, c_void_p, c_void_p, c_void_p]),

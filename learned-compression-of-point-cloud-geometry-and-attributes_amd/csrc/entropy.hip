@@ -113,6 +113,50 @@ __global__ __launch_bounds__(256) void gc_dequantize_kernel(const int32_t* __res
     }
 }
 
+// The same preparation writing the planes the host coder reads directly, in stream order: rows permuted into the
+// canonical (b, x, y, z) order on the way (`perm`: output column j takes row perm[j]; the reference sorts the tensors,
+// utils.py:155-180), symbols as int16 and table indexes as uint8 — 3 bytes per symbol over PCIe instead of 8, one kernel
+// instead of prepare + two index_selects + a stack.  A symbol outside int16 raises *overflow (the caller then takes the
+// int32 path; escape coding makes such symbols legal, they just do not occur with sane scales).
+__global__ __launch_bounds__(256) void gc_encode_prep_packed_kernel(const float* __restrict__ y,
+                                                                    const float* __restrict__ params, int64_t n, int c,
+                                                                    const float* __restrict__ table, int levels,
+                                                                    const int32_t* __restrict__ perm,
+                                                                    int16_t* __restrict__ sym, uint8_t* __restrict__ idx,
+                                                                    int32_t* __restrict__ overflow) {
+    __shared__ float tb[256];
+    for (int i = threadIdx.x; i < levels; i += 256) tb[i] = table[i];
+    __syncthreads();
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t j = e / c;
+        const int ch = (int)(e - j * c);
+        const int64_t row = perm ? perm[j] : j;
+        const float scale = fmaxf(params[row * 2 * c + ch], SCALE_BOUND);
+        const float mean = params[row * 2 * c + c + ch];
+        int ix = levels - 1;
+        for (int i = 0; i < levels - 1; ++i) ix -= (scale <= tb[i]) ? 1 : 0;
+        const int64_t o = (int64_t)ch * n + j;
+        idx[o] = (uint8_t)ix;
+        if (sym) {
+            const float sv = rintf(y[row * c + ch] - mean);
+            if (!(sv >= -32768.0f && sv <= 32767.0f)) atomicOr(overflow, 1);
+            sym[o] = (int16_t)fminf(fmaxf(sv, -32768.0f), 32767.0f);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gc_dequantize_i16_kernel(const int16_t* __restrict__ sym,
+                                                                const float* __restrict__ params, int64_t n, int c,
+                                                                float* __restrict__ yhat) {
+    const int64_t total = n * c;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / c;
+        const int ch = (int)(e - row * c);
+        yhat[e] = (float)sym[(int64_t)ch * n + row] + params[row * 2 * c + c + ch];
+    }
+}
+
 __device__ __forceinline__ float std_cdf(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
 
 __global__ __launch_bounds__(256) void gc_forward_kernel(const float* __restrict__ y, const float* __restrict__ params,
@@ -170,6 +214,27 @@ int pcc_gc_encode_prep(const float* y, const float* params, int64_t n, int32_t c
     if (n <= 0) return PCC_OK;
     hipLaunchKernelGGL(gc_encode_prep_kernel, ELEMWISE_GRID(n * c), y, params, n, c, scale_table, levels, symbols,
                        indexes);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_gc_encode_prep_packed(const float* y, const float* params, int64_t n, int32_t c, const float* scale_table,
+                              int32_t levels, const int32_t* perm, int16_t* symbols, uint8_t* indexes, int32_t* overflow,
+                              void* stream) {
+    PCC_REQUIRE(levels >= 2 && levels <= 256, "pcc_gc_encode_prep_packed: levels %d out of range", levels);
+    PCC_REQUIRE(indexes != nullptr, "pcc_gc_encode_prep_packed: index plane required");
+    PCC_REQUIRE(symbols == nullptr || (y != nullptr && overflow != nullptr), "pcc_gc_encode_prep_packed: symbols need y and the overflow word");
+    if (overflow) PCC_CHECK_HIP(hipMemsetAsync(overflow, 0, sizeof(int32_t), as_stream(stream)));
+    if (n <= 0) return PCC_OK;
+    hipLaunchKernelGGL(gc_encode_prep_packed_kernel, ELEMWISE_GRID(n * c), y, params, n, c, scale_table, levels, perm, symbols,
+                       indexes, overflow);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_gc_dequantize_i16(const int16_t* symbols, const float* params, int64_t n, int32_t c, float* y_hat, void* stream) {
+    if (n <= 0) return PCC_OK;
+    hipLaunchKernelGGL(gc_dequantize_i16_kernel, ELEMWISE_GRID(n * c), symbols, params, n, c, y_hat);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -92,11 +92,12 @@ inline void put_bits(uint64_t& x, Writer& w, uint32_t val) {
 
 }  // namespace
 
-extern "C" {
-
-int64_t pcc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n, const int32_t* cdfs,
-                                     int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
-                                     uint8_t* out, int64_t out_cap) {
+// the coder proper, on the plane types the caller holds: int32 / int32 (compressai's argument types) or the packed
+// int16 symbols / uint8 indexes the GPU writes for the y stream (3 bytes per symbol over PCIe and through the cache)
+template <class SymT, class IdxT>
+static int64_t rans_encode(const SymT* symbols, const IdxT* indexes, int64_t n, const int32_t* cdfs,
+                           int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                           uint8_t* out, int64_t out_cap) {
     if (n < 0 || !out) { pcc::set_error("pcc_rans_encode_with_indexes: bad arguments"); return PCC_ERR_ARG; }
     // which tables does the stream touch, and what is the highest one?
     int32_t max_ix = -1;
@@ -155,9 +156,12 @@ int64_t pcc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* inde
     return nbytes;
 }
 
-int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
-                                 const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
-                                 const int32_t* offsets, int32_t* out_symbols) {
+// *narrowed (may be NULL for int32 output) is set when a decoded symbol does not fit SymT: the caller repeats the
+// decode with int32 output
+template <class SymT, class IdxT>
+static int rans_decode(const uint8_t* data, int64_t nbytes, const IdxT* indexes, int64_t n,
+                       const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                       const int32_t* offsets, SymT* out_symbols, int32_t* narrowed) {
     if (nbytes < 8 || (nbytes & 3)) { pcc::set_error("pcc_rans_decode_with_indexes: malformed stream length %lld", (long long)nbytes); return PCC_ERR_DATA; }
     int32_t max_ix = -1;
     for (int64_t i = 0; i < n; ++i) {
@@ -237,9 +241,39 @@ int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int3
             value = (int32_t)(raw >> 1);
             value = (raw & 1u) ? -value - 1 : value + maxv;
         }
-        out_symbols[i] = value + tb.offset;
+        const int32_t sym = value + tb.offset;
+        out_symbols[i] = (SymT)sym;
+        if (sizeof(SymT) < 4 && (int32_t)(SymT)sym != sym && narrowed) *narrowed = 1;
     }
     return PCC_OK;
+}
+
+extern "C" {
+
+int64_t pcc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, int64_t n, const int32_t* cdfs,
+                                     int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                                     uint8_t* out, int64_t out_cap) {
+    return rans_encode<int32_t, int32_t>(symbols, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, out, out_cap);
+}
+
+int64_t pcc_rans_encode_with_indexes_i16u8(const int16_t* symbols, const uint8_t* indexes, int64_t n, const int32_t* cdfs,
+                                           int32_t cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets,
+                                           uint8_t* out, int64_t out_cap) {
+    return rans_encode<int16_t, uint8_t>(symbols, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, out, out_cap);
+}
+
+int pcc_rans_decode_with_indexes(const uint8_t* data, int64_t nbytes, const int32_t* indexes, int64_t n,
+                                 const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                 const int32_t* offsets, int32_t* out_symbols) {
+    return rans_decode<int32_t, int32_t>(data, nbytes, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, out_symbols, nullptr);
+}
+
+int pcc_rans_decode_with_indexes_u8i16(const uint8_t* data, int64_t nbytes, const uint8_t* indexes, int64_t n,
+                                       const int32_t* cdfs, int32_t cdf_stride, const int32_t* cdf_sizes,
+                                       const int32_t* offsets, int16_t* out_symbols, int32_t* narrowed) {
+    if (!narrowed) { pcc::set_error("pcc_rans_decode_with_indexes_u8i16: the narrowed flag is required"); return PCC_ERR_ARG; }
+    *narrowed = 0;
+    return rans_decode<int16_t, uint8_t>(data, nbytes, indexes, n, cdfs, cdf_stride, cdf_sizes, offsets, out_symbols, narrowed);
 }
 
 int pcc_pmf_to_quantized_cdf(const float* pmf, int32_t n, int32_t precision, int32_t* cdf) {

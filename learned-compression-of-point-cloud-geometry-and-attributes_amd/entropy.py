@@ -140,6 +140,29 @@ def _rans_encode(symbols, indexes, cdf, cdf_length, offset):
     check(nbytes)
 
 
+def _rans_encode_packed(symbols, indexes, cdf, cdf_length, offset):
+    """symbols int16 / indexes uint8 host arrays (the planes pcc_gc_encode_prep_packed wrote): identical bytes"""
+    L = _lib.lib()
+    n = symbols.size
+    for cap in (n + 4096, 4 * (3 * n + 4)):
+        out = np.empty(cap, dtype=np.uint8)
+        nbytes = L.pcc_rans_encode_with_indexes_i16u8(ptr(symbols), ptr(indexes), n, ptr(cdf), cdf.shape[1],
+                                                      ptr(cdf_length), ptr(offset), ptr(out), cap)
+        if nbytes >= 0:
+            return out[:nbytes].tobytes()
+    check(nbytes)
+
+
+def _rans_decode_packed(data, indexes, cdf, cdf_length, offset, out):
+    """indexes uint8 -> symbols into ``out`` (int16, pinned); returns False when a symbol did not fit int16"""
+    L = _lib.lib()
+    buf = np.frombuffer(data, dtype=np.uint8)
+    narrowed = np.zeros(1, dtype=np.int32)
+    check(L.pcc_rans_decode_with_indexes_u8i16(ptr(buf), len(data), ptr(indexes), indexes.size, ptr(cdf), cdf.shape[1],
+                                               ptr(cdf_length), ptr(offset), ptr(out), ptr(narrowed)))
+    return int(narrowed[0]) == 0
+
+
 def _rans_decode(data, indexes, cdf, cdf_length, offset):
     L = _lib.lib()
     indexes = np.ascontiguousarray(indexes, dtype=np.int32).reshape(-1)
@@ -432,12 +455,30 @@ class GaussianConditional(_EntropyModelBase):
         return finish
 
     def compress_features_begin(self, y_feats, params, perm=None):
-        """Two-phase form of compress_features (see EntropyBottleneck.compress_features_begin) -> finish() -> [bytes]"""
-        sym, idx = self.encode_prep(y_feats, params)
-        if perm is not None:
-            p = perm.long()
-            sym, idx = sym.index_select(1, p), idx.index_select(1, p)
-        return self._encode_begin(sym, idx)
+        """Two-phase form of compress_features (see EntropyBottleneck.compress_features_begin) -> finish() -> [bytes].
+        One kernel writes the int16 symbol plane and the uint8 index plane in stream order (rows permuted on the way)
+        into one buffer, one copy takes it to the host: 3 bytes per symbol instead of 8.  Symbols beyond int16 (legal,
+        escape-coded, not seen with sane scales) fall back to the int32 planes."""
+        n, c = y_feats.shape
+        dev = y_feats.device
+        cn = c * n
+        flag_at = (3 * cn + 3) // 4 * 4
+        packed = torch.empty(flag_at + 4, dtype=torch.uint8, device=dev)
+        table = self.scale_table.to(dev).contiguous()
+        base = packed.data_ptr()
+        check(_lib.lib().pcc_gc_encode_prep_packed(ptr(y_feats.contiguous()), ptr(params.contiguous()), n, c, ptr(table), table.numel(),
+                                                   ptr(None if perm is None else perm.contiguous()), base, base + 2 * cn, base + flag_at,
+                                                   _lib.stream()))
+        host, ev = _to_host_async(packed, "gc_packed")
+        cdf, cdf_len, off = self.tables()
+
+        def finish():
+            ev.synchronize()
+            if int(host[flag_at:flag_at + 4].view(np.int32)[0]):
+                return self.compress_features(y_feats, params, perm)             # int32 planes
+            return [_rans_encode_packed(host[:2 * cn].view(np.int16), host[2 * cn:3 * cn], cdf, cdf_len, off)]
+
+        return finish
 
     def decompress_features(self, strings, params, c):
         """params rows must be in the bitstream's row order.  -> y_hat [N, C]."""
@@ -451,13 +492,21 @@ class GaussianConditional(_EntropyModelBase):
         import threading
         n = params.shape[0]
         dev = params.device
-        idx_host = _to_host(self.indexes_for(params, c), "gc_idx")
+        cn = c * n
+        idx_dev = torch.empty(cn, dtype=torch.uint8, device=dev)
+        table = self.scale_table.to(dev).contiguous()
+        check(_lib.lib().pcc_gc_encode_prep_packed(None, ptr(params.contiguous()), n, c, ptr(table), table.numel(), None, None,
+                                                   ptr(idx_dev), None, _lib.stream()))
+        idx_host = _to_host(idx_dev, "gc_idx8")
+        sym_host = _pinned("gc_sym16", cn, torch.int16)
         cdf, cdf_len, off = self.tables()
         box = {}
 
         def work():
             try:
-                box["sym"] = _rans_decode(strings[0], idx_host, cdf, cdf_len, off)
+                box["fits"] = _rans_decode_packed(strings[0], idx_host, cdf, cdf_len, off, sym_host.numpy())
+                if not box["fits"]:                                              # a symbol beyond int16: int32 planes
+                    box["sym"] = _rans_decode(strings[0], idx_host.astype(np.int32), cdf, cdf_len, off)
             except BaseException as e:      # re-raised on the caller's thread
                 box["err"] = e
 
@@ -468,9 +517,14 @@ class GaussianConditional(_EntropyModelBase):
             th.join()
             if "err" in box:
                 raise box["err"]
-            sym = _to_device(box["sym"].reshape(c, n), dev, "gc_sym_up")
             yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
-            check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
+            if box["fits"]:
+                sym = sym_host.to(dev, non_blocking=True)
+                check(_lib.lib().pcc_gc_dequantize_i16(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
+                torch.cuda.current_stream(dev).synchronize()                     # the pinned plane is reused by the next frame
+            else:
+                sym = _to_device(box["sym"].reshape(c, n), dev, "gc_sym_up")
+                check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
             return yhat
 
         return finish

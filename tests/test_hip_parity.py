@@ -501,3 +501,44 @@ def test_gaussian_conditional_kernels(pcc, oracle_codec):
     assert strings[0] == o.compress(y3, want_idx, m3)[0]
     back = gc.decompress_features(strings, dev(params), c).cpu()
     assert torch.equal(back.t().unsqueeze(0), o.decompress(strings, want_idx, m3))
+
+
+def test_gaussian_conditional_packed_planes(pcc, oracle_codec):
+    """pcc_gc_encode_prep_packed: int16 symbols / uint8 indexes in stream order (rows permuted on the way) equal the
+    int32 planes of pcc_gc_encode_prep after index_select; the overflow word reports symbols beyond int16; the packed
+    compress path codes the same bytes as the int32 path, and its decode returns the same y_hat"""
+    from pcc_amd._lib import ptr, check, stream
+    model = pcc.synthetic.make_model(0, DEV)
+    model.update()
+    gc = model.entropy_model.gaussian_conditional
+    L = pcc.lib()
+    torch.manual_seed(1)
+    n, c = 777, 128
+    y = (torch.randn(n, c) * 6).to(DEV)
+    params = torch.cat([torch.rand(n, c) * 3 + 0.05, torch.randn(n, c)], dim=1).to(DEV)
+    perm = torch.randperm(n).to(torch.int32).to(DEV)
+    sym32, idx32 = gc.encode_prep(y, params)
+    sym32, idx32 = sym32.index_select(1, perm.long()), idx32.index_select(1, perm.long())
+    cn = c * n
+    sym16 = torch.empty(cn, dtype=torch.int16, device=DEV)
+    idx8 = torch.empty(cn, dtype=torch.uint8, device=DEV)
+    flag = torch.ones(1, dtype=torch.int32, device=DEV)
+    table = gc.scale_table.to(DEV).contiguous()
+    check(L.pcc_gc_encode_prep_packed(ptr(y), ptr(params), n, c, ptr(table), table.numel(), ptr(perm), ptr(sym16), ptr(idx8), ptr(flag),
+                                      stream()))
+    assert int(flag.item()) == 0
+    assert torch.equal(sym16.reshape(c, n).to(torch.int32), sym32) and torch.equal(idx8.reshape(c, n).to(torch.int32), idx32)
+    y_big = y.clone()
+    y_big[5, 7] = 1e6
+    check(L.pcc_gc_encode_prep_packed(ptr(y_big), ptr(params), n, c, ptr(table), table.numel(), ptr(perm), ptr(sym16), ptr(idx8),
+                                      ptr(flag), stream()))
+    assert int(flag.item()) == 1
+    # the two compress paths: same bytes (the big symbol takes the int32 planes inside compress_features_begin)
+    for feats in (y, y_big):
+        a = gc.compress_features_begin(feats, params, perm)()
+        b = gc.compress_features(feats, params, perm)
+        assert a == b
+        p_sorted = params.index_select(0, perm.long())
+        back = gc.decompress_features(a, p_sorted, c)
+        want = torch.round(feats.index_select(0, perm.long()) - p_sorted[:, c:]) + p_sorted[:, c:]
+        assert torch.equal(back, want)

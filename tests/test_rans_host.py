@@ -62,3 +62,23 @@ def test_malformed_inputs_are_reported_not_crashed(pcc):
         pe._rans_decode(b"\x00\x01\x02", idx, cdf, cdf_length, offset)          # not a multiple of 4 bytes
     with pytest.raises(RuntimeError):
         pe._rans_decode(b"\x00" * 8, np.array([-1], dtype=np.int32), cdf, cdf_length, offset)
+
+
+@pytest.mark.parametrize("n,spread,seed", [(1, 0.3, 0), (4099, 0.3, 1), (50000, 1.5, 2)])
+def test_packed_planes_code_the_same_bytes(pcc, n, spread, seed):
+    """the int16-symbol / uint8-index entry points (what the GPU writes for the y stream) against the int32 ones and
+    the oracle: identical bytes, exact round trip; a symbol beyond int16 is reported, not truncated"""
+    from pcc_amd import entropy as pe
+    cdf, cdf_length, offset = _tables()
+    rng = np.random.default_rng(seed)
+    sym, idx = _draw(rng, n, cdf_length, offset, spread)
+    data = pe._rans_encode_packed(sym.astype(np.int16), idx.astype(np.uint8), cdf, cdf_length, offset)
+    assert data == pe._rans_encode(sym, idx, cdf, cdf_length, offset) == orans.encode_with_indexes(sym, idx, cdf, cdf_length, offset)
+    out = np.empty(n, dtype=np.int16)
+    assert pe._rans_decode_packed(data, idx.astype(np.uint8), cdf, cdf_length, offset, out)
+    assert np.array_equal(out.astype(np.int32), sym)
+    big = sym.copy()
+    big[n // 2] = 40000                                                        # escape-coded, beyond int16
+    data = pe._rans_encode(big, idx, cdf, cdf_length, offset)
+    assert not pe._rans_decode_packed(data, idx.astype(np.uint8), cdf, cdf_length, offset, out)
+    assert np.array_equal(pe._rans_decode(data, idx, cdf, cdf_length, offset), big)
