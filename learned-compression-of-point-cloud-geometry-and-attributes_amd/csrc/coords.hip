@@ -530,10 +530,22 @@ __global__ __launch_bounds__(256) void compact_index_kernel(const uint8_t* __res
     if (keep && coords) reinterpret_cast<int4*>(out_coords)[p] = reinterpret_cast<const int4*>(coords)[i];
 }
 
+// kept rows move as 16-byte pieces: one thread per (row, 4 channels); dropped rows cost one mask byte per piece
 __global__ __launch_bounds__(256) void compact_feats_kernel(const uint8_t* __restrict__ mask,
                                                             const int32_t* __restrict__ pos, int64_t n, int c,
                                                             const float* __restrict__ feats,
                                                             float* __restrict__ out_feats) {
+    if ((c & 3) == 0) {
+        const int c4 = c >> 2;
+        const int64_t total = n * c4;
+        const float4* src = reinterpret_cast<const float4*>(feats);
+        float4* dst = reinterpret_cast<float4*>(out_feats);
+        for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t r = e / c4;
+            if (mask[r]) dst[(int64_t)pos[r] * c4 + (e - r * c4)] = src[e];
+        }
+        return;
+    }
     const int64_t total = n * c;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = e / c;
@@ -723,8 +735,8 @@ int pcc_compact_rows(const uint8_t* mask, int64_t n, const int32_t* coords, int3
         hipLaunchKernelGGL(compact_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, mask, flags, n, coords,
                            out_coords, new_index);
     if (feats && c > 0)
-        hipLaunchKernelGGL(compact_feats_kernel, dim3(blocks_for(n * c, 256, 65536)), dim3(256), 0, st, mask, flags, n, c,
-                           feats, out_feats);
+        hipLaunchKernelGGL(compact_feats_kernel, dim3(blocks_for((c & 3) == 0 ? n * (c / 4) : n * c, 256, 65536)), dim3(256), 0, st,
+                           mask, flags, n, c, feats, out_feats);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

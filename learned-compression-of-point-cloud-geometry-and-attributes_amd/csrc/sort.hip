@@ -53,14 +53,16 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
     return v;
 }
 
-template <class K>
+// ROUNDS: rounds of 64 keys per wave (compile-time: the sweeps are unrolled over the register-resident keys; a 1.2 k-row
+// set runs the 1-round instance instead of 16 mostly predicated-off rounds)
+template <class K, int ROUNDS>
 __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* ka, K* kb, int32_t* va, int32_t* vb, int iota, int n,
                                                                            int begin_bit, int end_bit, int passes) {
     __shared__ int cnt[RS_SMALL_WAVES][256];
     __shared__ int tot[256];
     __shared__ int wsum[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int chunk = ((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64 * 64;      // <= 64 * RS_SMALL_ROUNDS
+    const int chunk = ((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64 * 64;      // <= 64 * ROUNDS
     const int lo = w * chunk < n ? w * chunk : n;
     const int hi = lo + chunk < n ? lo + chunk : n;
     const uint64_t lt = (1ull << lane) - 1ull;
@@ -72,10 +74,10 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
         const int shift = begin_bit + 8 * p;
         const unsigned dmask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
         // the wave's chunk in registers: one batch of loads per pass
-        K key[RS_SMALL_ROUNDS];
-        int32_t val[RS_SMALL_ROUNDS];
+        K key[ROUNDS];
+        int32_t val[ROUNDS];
 #pragma unroll
-        for (int j = 0; j < RS_SMALL_ROUNDS; ++j) {
+        for (int j = 0; j < ROUNDS; ++j) {
             const int i = lo + j * 64 + lane;
             key[j] = (i < hi) ? src[i] : (K)0;
             val[j] = (i < hi) ? ((iota && p == 0) ? i : vs[i]) : 0;
@@ -83,7 +85,7 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
         for (int i = t; i < RS_SMALL_WAVES * 256; i += RS_SMALL_THREADS) (&cnt[0][0])[i] = 0;
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RS_SMALL_ROUNDS; ++j)
+        for (int j = 0; j < ROUNDS; ++j)
             if (lo + j * 64 + lane < hi) atomicAdd(&cnt[w][(unsigned)(key[j] >> shift) & dmask], 1);
         __syncthreads();
         // digit t: chunk bases (exclusive over the waves, input order) and the digit's total
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* k
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RS_SMALL_ROUNDS; ++j) {
+        for (int j = 0; j < ROUNDS; ++j) {
             const int i = lo + j * 64 + lane;
             const bool active = i < hi;
             const unsigned d = (unsigned)(key[j] >> shift) & dmask;
@@ -277,8 +279,16 @@ static int radix_sort_pairs(K* ka, K* kb, int32_t* va, int32_t* vb, bool iota, i
     PCC_REQUIRE(n < (1ll << 31), "radix sort: too many keys (%lld)", (long long)n);
     if (n <= 0) return PCC_OK;
     if (n <= RS_SMALL_N) {
-        hipLaunchKernelGGL(radix_sort_small_kernel<K>, dim3(1), dim3(RS_SMALL_THREADS), 0, st, ka, kb, va, vb, iota ? 1 : 0, (int)n, begin_bit,
-                           end_bit, passes);
+        const int rounds = (int)(((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
+#define PCC_RS_SMALL(R)                                                                                                         \
+    hipLaunchKernelGGL((radix_sort_small_kernel<K, R>), dim3(1), dim3(RS_SMALL_THREADS), 0, st, ka, kb, va, vb, iota ? 1 : 0, (int)n, \
+                       begin_bit, end_bit, passes)
+        if (rounds <= 1) PCC_RS_SMALL(1);
+        else if (rounds <= 2) PCC_RS_SMALL(2);
+        else if (rounds <= 4) PCC_RS_SMALL(4);
+        else if (rounds <= 8) PCC_RS_SMALL(8);
+        else PCC_RS_SMALL(16);
+#undef PCC_RS_SMALL
         PCC_LAUNCH_CHECK();
         return PCC_OK;
     }
