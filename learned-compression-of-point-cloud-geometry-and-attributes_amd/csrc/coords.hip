@@ -534,8 +534,8 @@ __global__ __launch_bounds__(256) void compact_index_kernel(const uint8_t* __res
 __global__ __launch_bounds__(256) void compact_feats_kernel(const uint8_t* __restrict__ mask,
                                                             const int32_t* __restrict__ pos, int64_t n, int c,
                                                             const float* __restrict__ feats,
-                                                            float* __restrict__ out_feats) {
-    if ((c & 3) == 0) {
+                                                            float* __restrict__ out_feats, int vec) {
+    if (vec) {
         const int c4 = c >> 2;
         const int64_t total = n * c4;
         const float4* src = reinterpret_cast<const float4*>(feats);
@@ -735,8 +735,11 @@ int pcc_compact_rows(const uint8_t* mask, int64_t n, const int32_t* coords, int3
         hipLaunchKernelGGL(compact_index_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, mask, flags, n, coords,
                            out_coords, new_index);
     if (feats && c > 0)
-        hipLaunchKernelGGL(compact_feats_kernel, dim3(blocks_for((c & 3) == 0 ? n * (c / 4) : n * c, 256, 65536)), dim3(256), 0, st,
-                           mask, flags, n, c, feats, out_feats);
+    {
+        const int vec = (c & 3) == 0 && ((reinterpret_cast<uintptr_t>(feats) | reinterpret_cast<uintptr_t>(out_feats)) & 15) == 0;
+        hipLaunchKernelGGL(compact_feats_kernel, dim3(blocks_for(vec ? n * (c / 4) : n * c, 256, 65536)), dim3(256), 0, st,
+                           mask, flags, n, c, feats, out_feats, vec);
+    }
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -36,6 +36,26 @@ def _as_int_coords(coords):
     return coords.to(torch.int32).contiguous()
 
 
+_COUNT_BUFS = {}
+
+
+def _host_count():
+    """A page-locked int64 the device writes a row count into directly (zero-copy): reading it back takes a stream
+    synchronisation instead of a device-to-host copy plus one.  One per host thread (worker threads code frames
+    concurrently)."""
+    import threading
+    key = threading.get_ident()
+    buf = _COUNT_BUFS.get(key)
+    if buf is None:
+        buf = _COUNT_BUFS[key] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+    return buf
+
+
+def _read_count(buf, device):
+    torch.cuda.current_stream(device).synchronize()
+    return int(buf[0])
+
+
 class CoordMap:
     """A coordinate set of one tensor stride with its hashed-voxel table and cached kernel maps.
 
@@ -93,10 +113,10 @@ class CoordMap:
         vals = torch.empty(cap, dtype=torch.int32, device=dev)
         scratch = torch.empty(L.pcc_scan_scratch_elems(m), dtype=torch.int32, device=dev)
         out = torch.empty((max(m, 1), 4), dtype=torch.int32, device=dev)
-        count = torch.empty(1, dtype=torch.int64, device=dev)
+        count = _host_count()
         check(getattr(L, fn_name)(ptr(self.coords), self.n, *args, ptr(keys), ptr(vals), cap, ptr(scratch),
                                   ptr(out), ptr(count), _lib.stream()))
-        n_out = int(count.item())      # the one host sync of a coordinate-set construction
+        n_out = _read_count(count, dev)      # the one host sync of a coordinate-set construction
         return out[:n_out], (keys, vals, cap)
 
     def down(self):
@@ -288,14 +308,14 @@ def compact_rows(mask, coords=None, feats=None, want_index=False):
     n = mask.shape[0]
     dev = mask.device
     scratch = torch.empty(L.pcc_scan_scratch_elems(n), dtype=torch.int32, device=dev)
-    count = torch.empty(1, dtype=torch.int64, device=dev)
+    count = _host_count()
     out_c = torch.empty((n, 4), dtype=torch.int32, device=dev) if coords is not None else None
     c = feats.shape[1] if feats is not None else 0
     out_f = torch.empty((n, c), dtype=torch.float32, device=dev) if feats is not None else None
     new_index = torch.empty(n, dtype=torch.int32, device=dev) if want_index else None
     check(L.pcc_compact_rows(ptr(mask), n, ptr(coords), ptr(out_c), ptr(feats), c, ptr(out_f), ptr(new_index),
                              ptr(scratch), ptr(count), _lib.stream()))
-    m = int(count.item())
+    m = _read_count(count, dev)
     return (out_c[:m] if out_c is not None else None, out_f[:m] if out_f is not None else None, new_index, m)
 
 
