@@ -78,6 +78,11 @@ def parse():
     ap.add_argument("--bf16", action="store_true",
                     help="opt-in reduced-precision mode: bf16 operands on the wide convolutions (fp32 accumulation); NOT the "
                          "headline configuration — the reference computes in fp32 and so does the default run")
+    ap.add_argument("--x3", action="store_true",
+                    help="opt-in split-bf16 arithmetic (fp32 data, three-way bf16 split of both operands, six bf16 MFMA products with "
+                         "fp32 accumulation) on the wide convolutions for the WHOLE run; NOT the headline configuration — a default "
+                         "run reports this mode as the `split_bf16` sub-record beside the fp32 value")
+    ap.add_argument("--no-x3-record", action="store_true", help="skip the `split_bf16` sub-record of a default run")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -166,6 +171,8 @@ def main():
     model.update()
     if args.bf16:
         sp.set_infer_bf16(True)
+    if args.x3:
+        sp.set_infer_x3(True)
 
     cfg = {"config1": syn.CONFIG1, "config2": syn.CONFIG2, "mid": dict(grid=256, radius=100.0, half_width=0.5)}[args.workload]
     cfg = dict(cfg)
@@ -320,6 +327,45 @@ def main():
                                  "(per-item k and top-k), containers all-gathered; a different partition gives "
                                  "different numbers than whole-frame coding (parity target: the oracle on the same items)"}
 
+    # ---- second record, never `value`: the same frame with split-bf16 arithmetic on the wide convolutions ----
+    x3_record = None
+    if not blocks_mode and not args.bf16 and not args.x3 and not args.no_x3_record and rank == 0 and world == 1:
+        from pcc_amd.metrics import PointCloudMetric
+        res = cfg["grid"] - 1
+
+        def quality(rec_):
+            m_, _ = PointCloudMetric(x, rec_, resolution=res).compute_pointcloud_metrics(drop_duplicates=True)
+            return float(m_["sym_psnr_mse"]), float(m_["sym_y_psnr"])
+
+        f32_bpp = pcc_amd.utils.count_bits(last["strings"]) / N
+        f32_d1, f32_y = quality(last["rec"])
+        sp.set_infer_x3(True)
+        try:
+            te = td = 0.0
+            x_steps = max(1, min(5, args.steps))
+            for it in range(2 + x_steps):
+                Qx = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                xs, xshape, xk, xc = model.compress(x, Qx)
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                xrec = model.decompress(coordinates=xc, strings=xs, shape=xshape, k=xk)
+                torch.cuda.synchronize(); t2 = time.perf_counter()
+                if it >= 2:
+                    te += t1 - t0; td += t2 - t1
+        finally:
+            sp.set_infer_x3(False)
+        x_bpp = pcc_amd.utils.count_bits(xs) / N
+        x_d1, x_y = quality(xrec)
+        x3_record = {"value": N * x_steps / (te + td) / 1e6, "unit": "Mpoints/s", "steps": x_steps,
+                     "ms_per_step": (te + td) / x_steps * 1e3, "t_enc_ms": te / x_steps * 1e3, "t_dec_ms": td / x_steps * 1e3,
+                     "dtype": "f32 data and accumulation; products of the wide convolutions as 6 bf16 MFMA terms of an exact 3-way "
+                              "bf16 split of both operands (dropped terms < 3 x 2^-24 |x||w| per product)",
+                     "bpp": x_bpp, "d1_psnr_db": x_d1, "y_psnr_db": x_y,
+                     "vs_f32_same_frame": {"bpp_abs_diff": abs(x_bpp - f32_bpp), "d1_psnr_db_abs_diff": abs(x_d1 - f32_d1),
+                                           "y_psnr_db_abs_diff": abs(x_y - f32_y), "k_equal": bool(xk == last["k"])},
+                     "note": "opt-in (PCC_INFER_X3=1 / bench.py --x3); the headline `value` is the fp32-multiply run above; encoder "
+                             "and decoder must run in the same mode"}
+
     # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
     classes = {}
     pop_cache = {}
@@ -363,7 +409,9 @@ def main():
                            "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 "
                                   "correction (tools/pmc_traffic.py); replayed from the committed file, not measured in this run"}
         peak = MFMA_BF16_PEAK_TFLOPS if "[bf16]" in dom_name else MFMA_F32_PEAK_TFLOPS
-        if "[bf16]" in dom_name:
+        if "[x3]" in dom_name:
+            peak = MFMA_BF16_PEAK_TFLOPS / 6.0      # six bf16 products per algorithmic multiply-add
+        if "[bf16]" in dom_name or "[x3]" in dom_name:
             traffic = traffic_src = None               # the PMC passes were taken on the fp32 kernel
         roofline = {"bound": "mfma", "kernel": dom_name, "achieved": achieved, "peak": peak,
                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
@@ -379,7 +427,7 @@ def main():
         # the peak assumes 2.4 GHz; the delivered clock of this kernel class under load was measured in a separate
         # rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace pass of this command (profiles/r01_clock_under_load.json)
         cj = latest_profile("clock_under_load")
-        if args.workload == "config2" and "[bf16]" not in dom_name and cj is not None:
+        if args.workload == "config2" and "[bf16]" not in dom_name and "[x3]" not in dom_name and cj is not None:
             for key, val in cj.get("bench_config2_frame", {}).items():
                 if key.replace(" ", "").startswith(dom_name.replace(" ", "").rstrip(">")) and "mean_clock_GHz" in val:
                     roofline["peak_assumes_clock_ghz"] = 2.4
@@ -443,7 +491,9 @@ def main():
         "higher_is_better": True,
         "scaling": "strong" if blocks_mode else "weak",
         "vs_baseline": None,
-        "dtype": "bf16 operands on the wide convolutions, fp32 accumulation (opt-in mode, not the headline)" if args.bf16 else "f32",
+        "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation (opt-in mode, not the headline)" if args.bf16 else
+                  "f32 data; wide-convolution products as 6 bf16 MFMA terms of an exact 3-way split (opt-in mode, not the headline)" if args.x3
+                  else "f32"),
         "data": "synthetic",
         "config": {"workload": f"{args.workload}: {cfg['grid']}^3 voxel sphere shell r={cfg['radius']}, N={N} points/frame, "
                                f"q=(0.5,0.5), configs/Ours.yaml, {'weights from ' + os.path.basename(args.weights) if args.weights else 'seeded random weights'}, in-memory compress+decompress, "
@@ -459,6 +509,8 @@ def main():
     }
     if blocks_record is not None:
         out["blocks"] = blocks_record
+    if x3_record is not None:
+        out["split_bf16"] = x3_record
     if file_mode is not None:
         out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

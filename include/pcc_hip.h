@@ -153,6 +153,19 @@ int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint
                       const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                       int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
 
+/* Split-bf16 arithmetic on fp32 data (opt-in; the default convolution multiplies in fp32): every fp32 operand is
+ * the exact sum of three bf16 numbers; the weights are pre-split into three planes (pcc_conv_pack_weights_x3,
+ * pcc_conv_packed_elems_x3 bf16 elements), the gathered fp32 rows are split in registers, and the six products
+ * whose weight is at least 2^-16 of the leading one run on v_mfma_f32_32x32x16_bf16 with fp32 accumulation in a
+ * fixed order.  Same semantics, epilogue and determinism guarantees as pcc_conv_fwd; results differ from it by
+ * the size of an fp32 rounding per product (dropped terms < 3 x 2^-24 |x||w|).  cin % 32 == 0, cin <= 256, output
+ * width (rounded up to 32) a multiple of 64; encoder and decoder must use the same mode. */
+int64_t pcc_conv_packed_elems_x3(int32_t K, int32_t cin, int32_t cout);
+int pcc_conv_pack_weights_x3(const float* w, int32_t K, int32_t cin, int32_t cout, uint16_t* w_packed, void* stream);
+int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t* w_packed, const float* bias,
+                    const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
+                    int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
+
 /* Narrow-head convolution, second half (cout <= 4 on wide inputs: the occupancy logit of
  * model/blocks.py:94-98,142 and the q-map heads).  The caller first computes
  * scores[i, k*cout + c] = in[i] . W[k][:, c] for every INPUT row with one kernel_size-1 call of

@@ -83,6 +83,43 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
     }
 }
 
+// Split-bf16 ("x3") packing: every fp32 weight is the EXACT sum of three bf16 numbers (24 significand bits = 8 + 8 + 8,
+// by truncation: hi = top 16 bits of w, mid = top 16 bits of w - hi, lo = w - hi - mid).  Layout per (k, 32-channel chunk):
+// [plane hi|mid|lo][group of 8 channels][col][8 bf16] — one linear LDS-DMA per step, each 16-B fragment one MFMA operand.
+__device__ __forceinline__ void split_bf16x3(float x, unsigned short& hi, unsigned short& mid, unsigned short& lo) {
+    const uint32_t xb = __float_as_uint(x);
+    const uint32_t hb = xb & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hb);
+    const uint32_t mb = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mb);
+    hi = (unsigned short)(hb >> 16);
+    mid = (unsigned short)(mb >> 16);
+    lo = (unsigned short)(__float_as_uint(r2) >> 16);
+}
+
+__global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* __restrict__ w, int K, int cin, int cout,
+                                                              int cinp, int coutp, unsigned short* __restrict__ wp) {
+    const int64_t total = (int64_t)K * cinp * coutp;              // one thread per weight, three outputs
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(e & 7);
+        int64_t t = e >> 3;
+        const int col = (int)(t % coutp);
+        t /= coutp;
+        const int g = (int)(t & 3);
+        t >>= 2;
+        const int c = (int)(t % (cinp / 32));
+        const int k = (int)(t / (cinp / 32));
+        const int ci = 32 * c + 8 * g + j;
+        const float v = (ci < cin && col < cout) ? w[((int64_t)k * cin + ci) * cout + col] : 0.0f;
+        unsigned short hi, mid, lo;
+        split_bf16x3(v, hi, mid, lo);
+        const int64_t base = ((int64_t)k * (cinp / 32) + c) * 12;          // 12 (plane, group) blocks of coutp x 8
+        wp[((base + 0 * 4 + g) * coutp + col) * 8 + j] = hi;
+        wp[((base + 1 * 4 + g) * coutp + col) * 8 + j] = mid;
+        wp[((base + 2 * 4 + g) * coutp + col) * 8 + j] = lo;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // MFMA path
 // ---------------------------------------------------------------------------------------------
@@ -94,8 +131,8 @@ __global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __r
 #endif
 constexpr int A_LD_DMA = 32;   // LDS-DMA image: unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
 
-template <int BM, int BN>
-constexpr int conv_lds_bytes() { return 2 * (BM * A_LD_DMA + 8 * BN * 4) * (int)sizeof(float); }
+template <int BM, int BN, bool X3 = false>
+constexpr int conv_lds_bytes() { return 2 * (BM * A_LD_DMA + (X3 ? 12 : 8) * BN * 4) * (int)sizeof(float); }
 
 // 1 KB of zeros: the gather source of absent neighbours on the LDS-DMA path
 __device__ float g_zero_line[256] = {0.0f};   // cin <= 256: the per-step channel offset stays inside
@@ -392,16 +429,23 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false>
+// X3 (split-bf16 arithmetic on fp32 data, pcc_conv_fwd_x3): the A image is the fp32 one; after a lane's 8 consecutive
+// channels of a row land in registers they are split exactly into three bf16 vectors (hi, mid, lo: and / subtract / and /
+// subtract / pack), the weights come pre-split as three planes, and the six products whose weight is at least 2^-16 of the
+// leading one — lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, in that fixed order — go through v_mfma_f32_32x32x16_bf16
+// with fp32 accumulation: 12 MFMAs of 8 passes per 32 x 32 x 32 block instead of 16 of 16 (3/8 of the matrix-pipe time),
+// every bf16 product exact in fp32, the dropped terms below 3 x 2^-24 of |x||w| — the size of an fp32 rounding.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)           // the buffer builtins exist in the device pass only; the host pass needs just the stub
     constexpr int RPT = BM / 32;              // gather DMAs per thread and step (8 lanes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
     constexpr int A_ELEMS = BM * 32;          // unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
-    constexpr int W_ELEMS = 8 * BN * 4;
-    constexpr int W_LOADS = (8 * BN) / 256;
+    constexpr int W_ELEMS = (X3 ? 12 : 8) * BN * 4;
+    constexpr int W_LOADS = ((X3 ? 12 : 8) * BN) / 256;
     static_assert(WAVES_M * WAVES_N == 4 && MT >= 1 && MT <= 2 && NT >= 1 && W_LOADS >= 1, "bad tiling");
+    static_assert(!(BF16 && X3), "one operand mode at a time");
     // BF16: the same byte images — a step is 64 bf16 channels (128 B per gathered row, 8 groups of 8 channels per
     // weight column) instead of 32 floats, and each 16-B fragment feeds ONE v_mfma_f32_32x32x16_bf16 (8 k-values
     // per lane) instead of four v_mfma_f32_32x32x2_f32.  CCH then counts 64-channel chunks.
@@ -457,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
         __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * ESZ), BUF_FLAGS);
         __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(a.wp), 0, (int)((uint32_t)K * a.cin * a.coutp * ESZ), BUF_FLAGS);
+            const_cast<float*>(a.wp), 0, (int)((uint32_t)K * a.cin * a.coutp * (X3 ? 6 : ESZ)), BUF_FLAGS);
         __amdgpu_buffer_rsrc_t rsrc_n = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<int32_t*>(a.nbr), 0, HAS_NBR ? (int)(uint32_t)(a.n_out * K * 4) : 0, BUF_FLAGS);
 
@@ -485,8 +529,9 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             w_voff[j] = (uint32_t)((g * a.coutp + nt * BN + col) * 16);
         }
         const int wave_u = __builtin_amdgcn_readfirstlane(wid);
-        const uint32_t w_kstride = (uint32_t)(a.cin * ESZ / 16) * a.coutp * 16;   // bytes per kernel offset (16-B channel groups)
-        const uint32_t w_cstride = (uint32_t)8 * a.coutp * 16;             // bytes per 32-channel chunk
+        const uint32_t w_kstride = X3 ? (uint32_t)(a.cin / 32) * 12u * a.coutp * 16u
+                                      : (uint32_t)(a.cin * ESZ / 16) * a.coutp * 16;   // bytes per kernel offset (16-B channel groups)
+        const uint32_t w_cstride = (uint32_t)(X3 ? 12 : 8) * a.coutp * 16;             // bytes per chunk
         const uint32_t a_row_bytes = (uint32_t)a.cin * ESZ;
 
         auto load_idx = [&](int k) {
@@ -530,7 +575,74 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
         }
         auto lds4 = [&](uint32_t addr) { return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(smem) + addr); };
 
+        // X3: lane (r, h) needs, for k16-step q, channels 16 q + 8 h .. + 7 of its rows = 16-B slots 4 q + 2 h and + 1
+        uint32_t a3_addr[2][2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+                    a3_addr[b][q][e] = (uint32_t)((b * A_ELEMS + (wrow + r) * 32 + ((4 * q + 2 * h + e) ^ sw) * 4) * 4);
+        auto split8 = [&](const f32x4& lo4, const f32x4& hi4, bf16x8& ph, bf16x8& pm, bf16x8& pl) {
+            uint32_t hb[8], mb[8], lb[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = j < 4 ? lo4[j] : hi4[j - 4];
+                hb[j] = __float_as_uint(x) & 0xFFFF0000u;
+                const float r1 = x - __uint_as_float(hb[j]);
+                mb[j] = __float_as_uint(r1) & 0xFFFF0000u;
+                lb[j] = __float_as_uint(r1 - __uint_as_float(mb[j]));
+            }
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 vh, vm, vl;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {          // element 2 d in the low half, 2 d + 1 in the high half
+                vh[d] = __builtin_amdgcn_perm(hb[2 * d + 1], hb[2 * d], 0x07060302u);
+                vm[d] = __builtin_amdgcn_perm(mb[2 * d + 1], mb[2 * d], 0x07060302u);
+                vl[d] = __builtin_amdgcn_perm(lb[2 * d + 1], lb[2 * d], 0x07060302u);
+            }
+            ph = __builtin_bit_cast(bf16x8, vh);
+            pm = __builtin_bit_cast(bf16x8, vm);
+            pl = __builtin_bit_cast(bf16x8, vl);
+        };
+        auto compute_live_x3 = [&](auto bufc, auto live_tag) {
+            constexpr int buf = decltype(bufc)::value;
+            constexpr unsigned LIVE = decltype(live_tag)::value;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bf16x8 ah[MT], am[MT], al[MT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+                    if ((LIVE >> m) & 1u)
+                        split8(lds4(a3_addr[buf][q][0] + 32 * m * 32 * 4), lds4(a3_addr[buf][q][1] + 32 * m * 32 * 4), ah[m], am[m], al[m]);
+                bf16x8 bh[NT], bm[NT], bl[NT];
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    const uint32_t wb = w_addr[buf] + (uint32_t)((2 * q * BN + 32 * n) * 16);
+                    bh[n] = __builtin_bit_cast(bf16x8, lds4(wb));
+                    bm[n] = __builtin_bit_cast(bf16x8, lds4(wb + 4 * BN * 16));
+                    bl[n] = __builtin_bit_cast(bf16x8, lds4(wb + 8 * BN * 16));
+                }
+#define PCC_X3_TERM(A, B)                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n) if ((LIVE >> m) & 1u)     \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m], B[n], acc[m][n], 0, 0, 0)
+                PCC_X3_TERM(al, bh);
+                PCC_X3_TERM(ah, bl);
+                PCC_X3_TERM(am, bm);
+                PCC_X3_TERM(am, bh);
+                PCC_X3_TERM(ah, bm);
+                PCC_X3_TERM(ah, bh);
+#undef PCC_X3_TERM
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
         auto compute_live = [&](auto bufc, auto live_tag) {
+            if constexpr (X3) {
+                compute_live_x3(bufc, live_tag);
+                return;
+            }
             constexpr int buf = decltype(bufc)::value;
             constexpr unsigned LIVE = decltype(live_tag)::value;
             f32x4 av[2][MT], bv[2][NT];
@@ -810,11 +922,11 @@ static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     return PCC_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false>
 static int launch_mfma_buf_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16>;
-    const int lds = conv_lds_bytes<BM, BN>();
+    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16, X3>;
+    const int lds = conv_lds_bytes<BM, BN, X3>();
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -864,6 +976,22 @@ static int launch_mfma_bf16(const ConvArgs& a, hipStream_t st) {
     }
 #undef PCC_BF16_CASE
     pcc::set_error("pcc_conv_fwd_bf16: cin=%d not supported (multiples of 64 up to 256)", a.cin);
+    return PCC_ERR_UNSUPPORTED;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_mfma_x3(const ConvArgs& a, hipStream_t st) {
+#define PCC_X3_CASE(C)                                                                                         \
+    case C:                                                                                                    \
+        return a.nbr ? launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, C, true, false, true>(a, st)             \
+                     : launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, C, false, false, true>(a, st);
+    switch (a.cin / 32) {
+        PCC_X3_CASE(1) PCC_X3_CASE(2) PCC_X3_CASE(3) PCC_X3_CASE(4)
+        PCC_X3_CASE(5) PCC_X3_CASE(6) PCC_X3_CASE(7) PCC_X3_CASE(8)
+        default: break;
+    }
+#undef PCC_X3_CASE
+    pcc::set_error("pcc_conv_fwd_x3: cin=%d not supported (multiples of 32 up to 256)", a.cin);
     return PCC_ERR_UNSUPPORTED;
 }
 
@@ -944,6 +1072,49 @@ int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint
     if (a.coutp % 128 == 0) return launch_mfma_bf16<64, 128, 2, 2>(a, st);
     if (a.coutp % 64 == 0) return launch_mfma_bf16<128, 64, 2, 2>(a, st);
     return launch_mfma_bf16<128, 32, 4, 1>(a, st);
+}
+
+int64_t pcc_conv_packed_elems_x3(int32_t K, int32_t cin, int32_t cout) {
+    return (int64_t)K * round_up32(cin) * round_up32(cout) * 3;
+}
+
+int pcc_conv_pack_weights_x3(const float* w, int32_t K, int32_t cin, int32_t cout, uint16_t* w_packed, void* stream) {
+    PCC_REQUIRE(K >= 1 && cin >= 1 && cout >= 1, "pcc_conv_pack_weights_x3: bad shape");
+    const int cinp = round_up32(cin), coutp = round_up32(cout);
+    const int64_t total = (int64_t)K * cinp * coutp;
+    hipLaunchKernelGGL(pack_weights_x3_kernel, dim3(blocks_for(total, 256, 4096)), dim3(256), 0, as_stream(stream), w, K, cin,
+                       cout, cinp, coutp, w_packed);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t* w_packed, const float* bias, const int32_t* nbr,
+                    const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
+                    int32_t act, const float* film, const float* residual, void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd_x3: K=%d out of range", K);
+    PCC_REQUIRE(cin % 32 == 0 && cin <= 256, "pcc_conv_fwd_x3: cin must be a multiple of 32 up to 256 (got %d)", cin);
+    PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd_x3: nbr == NULL needs K == 1 and n_in == n_out");
+    PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd_x3: bad activation %d", act);
+    PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd_x3: packed weights required");
+    PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(w_packed)) & 15) == 0,
+                "pcc_conv_fwd_x3: fin and w_packed must be 16-byte aligned (16-byte LDS-DMA loads)");
+    if (n_out <= 0) return PCC_OK;
+    ConvArgs a;
+    a.fin = fin; a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
+    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout; a.film = film; a.residual = residual;
+    a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 0;
+    a.debug = 0;
+    PCC_REQUIRE((uint64_t)n_in * cin * 4 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB && (uint64_t)K * cin * a.coutp * 6 <= BUF_OOB,
+                "pcc_conv_fwd_x3: operands of 4 GiB and more are not supported");
+    hipStream_t st = as_stream(stream);
+    static int bn64 = -1;        // PCC_X3_TILE=64: 64-wide column tiles everywhere (A/B)
+    if (bn64 < 0) { const char* e = getenv("PCC_X3_TILE"); bn64 = (e && atoi(e) == 64) ? 1 : 0; }
+    const int64_t wgs128 = ((a.n_out + 63) / 64) * (a.coutp / 128);
+    if (a.coutp % 128 == 0 && (wgs128 < 768 || bn64)) return launch_mfma_x3<64, 64, 2, 2>(a, st);
+    if (a.coutp % 128 == 0) return launch_mfma_x3<64, 128, 2, 2>(a, st);
+    if (a.coutp % 64 == 0) return launch_mfma_x3<128, 64, 2, 2>(a, st);
+    pcc::set_error("pcc_conv_fwd_x3: cout=%d not supported (output width rounded up to 32 must be a multiple of 64)", cout);
+    return PCC_ERR_UNSUPPORTED;
 }
 
 int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int32_t K, int32_t cout, const float* bias,

@@ -355,6 +355,8 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     n_out = out_map.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
     bf16 = INFER_BF16 and cin % 64 == 0 and x_feats.shape[0] * cin * 2 < 0xFFFFF000
+    x3 = (INFER_X3 and not bf16 and ((cout + 31) // 32 * 32) % 64 == 0 and x_feats.shape[0] * cin * 4 < 0xFFFFF000
+          and (nbr is None or n_out * K * 4 < 0xFFFFF000))
     prof = PROFILER
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -364,13 +366,17 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         xb = x_feats.to(torch.bfloat16)
         check(L.pcc_conv_fwd_bf16(ptr(xb), x_feats.shape[0], cin, ptr(layer.weights_bf16(out_channels)), ptr(bias), ptr(nbr),
                                   ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+    elif x3:
+        check(L.pcc_conv_fwd_x3(ptr(x_feats), x_feats.shape[0], cin, ptr(layer.weights_x3(out_channels)), ptr(bias), ptr(nbr),
+                                ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     else:
         check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
                              ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     if prof is not None:
         ev1.record()
         name = conv_kernel_name(cin, cout, n_out, nbr is not None)
-        prof.append((name.replace("conv_mfma_buf_kernel", "conv_mfma_buf_kernel[bf16]") if bf16 else name, cin, cout,
+        tag = "[bf16]" if bf16 else "[x3]" if x3 else ""
+        prof.append((name.replace("conv_mfma_buf_kernel", "conv_mfma_buf_kernel" + tag), cin, cout,
                      pairs if pairs is not None else n_out, n_out, ev0, ev1, gmask))
     return out
 
@@ -417,6 +423,19 @@ INFER_BF16 = os.environ.get("PCC_INFER_BF16", "0") == "1"
 def set_infer_bf16(enabled):
     global INFER_BF16
     INFER_BF16 = bool(enabled)
+
+
+# Opt-in split-bf16 arithmetic on fp32 data (never the default, never the headline number): the wide convolutions split
+# every fp32 operand exactly into three bf16 numbers and run the six significant products on v_mfma_f32_32x32x16_bf16 with
+# fp32 accumulation (csrc/conv.hip, X3) — fp32-class results (dropped terms < 3 x 2^-24 per product) at 3/8 of the fp32
+# MFMA time.  Features, gathers, epilogues, entropy models and streams stay fp32; encoder and decoder must run in the same
+# mode.  PCC_INFER_X3=1 / set_infer_x3().
+INFER_X3 = os.environ.get("PCC_INFER_X3", "0") == "1"
+
+
+def set_infer_x3(enabled):
+    global INFER_X3
+    INFER_X3 = bool(enabled)
 
 
 # Optional launch log for bench.py: a list that receives one tuple per convolution launch
@@ -512,6 +531,20 @@ class _ConvBase(nn.Module):
         check(L.pcc_conv_pack_weights_bf16(ptr(w), K, cin, cout, ptr(wpb), _lib.stream()))
         self._packed["b"] = (key, wpb)
         return wpb
+
+    def weights_x3(self, out_channels=None):
+        """three-plane bf16 packing of the kernel (opt-in split-bf16 arithmetic), cached like weights()"""
+        key = ("x3", self.kernel._version, self.kernel.data_ptr(), out_channels)
+        hit = self._packed.get("x")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w, _, _ = self.weights(out_channels)
+        K, cin, cout = w.shape
+        L = _lib.lib()
+        wpx = torch.empty(L.pcc_conv_packed_elems_x3(K, cin, cout), dtype=torch.bfloat16, device=w.device)
+        check(L.pcc_conv_pack_weights_x3(ptr(w), K, cin, cout, ptr(wpx), _lib.stream()))
+        self._packed["x"] = (key, wpx)
+        return wpx
 
     def narrow_weights(self, out_channels=None):
         """Kernel re-laid-out for the narrow-head path: [1, cin, K*cout] (+ MFMA packing), bias, K, cout."""

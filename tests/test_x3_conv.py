@@ -1,0 +1,140 @@
+"""Split-bf16 arithmetic on fp32 data (pcc_conv_fwd_x3, opt-in PCC_INFER_X3): every fp32 operand is split exactly into
+three bf16 numbers and the six significant products run on the bf16 MFMA with fp32 accumulation.  Checked here:
+the split is exact, the convolution agrees with a float64 evaluation as well as the fp32 MFMA kernel does, the fused
+epilogue is unchanged, results are deterministic and row-order invariant, and the whole codec in this mode meets the
+same oracle parity bounds as the fp32 codec (bpp 2e-3, D1 / Y-PSNR 1e-3 dB) with encoder and decoder agreeing bit for
+bit."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import nn as on
+from oracle.codec import count_bits
+from oracle.metrics import pc_metrics
+from _parity import assert_psnr_parity, voxel_flips
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def shell(grid=36, radius=13.0, thick=0.9):
+    g = np.stack(np.meshgrid(*[np.arange(grid)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    keep = np.abs(np.linalg.norm(g - (grid - 1) / 2, axis=1) - radius) < thick
+    return np.concatenate([np.zeros((int(keep.sum()), 1), np.int32), g[keep].astype(np.int32)], axis=1)
+
+
+def test_weight_planes_sum_to_the_weights_exactly(pcc):
+    from pcc_amd import _lib
+    from pcc_amd._lib import check, ptr
+    L = pcc.lib()
+    torch.manual_seed(0)
+    K, cin, cout = 27, 64, 128
+    W = (torch.randn(K, cin, cout) * torch.exp(torch.randn(K, cin, cout) * 3)).to(DEV).contiguous()      # wide dynamic range
+    W[0, 0, :4] = torch.tensor([0.0, -0.0, 1.0, -3.0e-30], device=DEV)
+    wp = torch.empty(L.pcc_conv_packed_elems_x3(K, cin, cout), dtype=torch.bfloat16, device=DEV)
+    check(L.pcc_conv_pack_weights_x3(ptr(W), K, cin, cout, ptr(wp), _lib.stream()))
+    planes = wp.reshape(K, cin // 32, 3, 4, cout, 8).float()                      # [k][chunk][plane][group][col][j]
+    total = planes[:, :, 0] + planes[:, :, 1] + planes[:, :, 2]                    # fp32 adds of exact pieces, big to small
+    back = total.permute(0, 1, 2, 4, 3).reshape(K, cin, cout)                      # ci = 32 chunk + 8 group + j
+    assert torch.equal(back, W)
+
+
+@pytest.mark.parametrize("cin,cout,ksize", [(64, 64, 3), (128, 128, 3), (128, 256, 3), (64, 128, 3), (128, 64, 3), (192, 256, 3),
+                                             (96, 64, 3), (32, 64, 3), (128, 128, 1)])
+def test_x3_conv_is_fp32_accurate(pcc, cin, cout, ksize):
+    from pcc_amd import _lib
+    from pcc_amd._lib import check, ptr
+    L = pcc.lib()
+    torch.manual_seed(cin * 7 + cout)
+    c = shell()
+    n = c.shape[0]
+    K = ksize ** 3
+    F = torch.randn(n, cin) * torch.exp(torch.randn(n, 1))
+    W = torch.randn(K, cin, cout) / np.sqrt(cin * 10)
+    b = torch.randn(cout) * 0.1
+    film = torch.cat([1 + 0.1 * torch.randn(n, cout), 0.1 * torch.randn(n, cout)], dim=1)
+    res = torch.randn(n, cout)
+    m = pcc.CoordMap(torch.from_numpy(c).to(DEV), 1)
+    if ksize == 1:
+        nbr = order = gmask = None
+        ref64 = F.double() @ W.double()[0] + b.double()
+    else:
+        nbr, order, gmask, _ = m.ordered_kernel_map(m, ksize)
+        ref64 = on._apply_conv(F.double(), W.double(), b.double().reshape(1, -1), oc.kernel_map(c, c, ksize, 1), n)
+    ref64 = torch.relu(ref64 * film[:, :cout].double() + film[:, cout:].double()) + res.double()
+    Wd = W.to(DEV).contiguous()
+    wp3 = torch.empty(L.pcc_conv_packed_elems_x3(K, cin, cout), dtype=torch.bfloat16, device=DEV)
+    check(L.pcc_conv_pack_weights_x3(ptr(Wd), K, cin, cout, ptr(wp3), _lib.stream()))
+    wp = torch.empty(L.pcc_conv_packed_elems(K, cin, cout), dtype=torch.float32, device=DEV)
+    check(L.pcc_conv_pack_weights(ptr(Wd), K, cin, cout, ptr(wp), _lib.stream()))
+    x, bd, fd, rd = F.to(DEV).contiguous(), b.to(DEV), film.to(DEV).contiguous(), res.to(DEV).contiguous()
+    out3 = torch.empty((n, cout), dtype=torch.float32, device=DEV)
+    out32 = torch.empty_like(out3)
+    check(L.pcc_conv_fwd_x3(ptr(x), n, cin, ptr(wp3), ptr(bd), ptr(nbr), ptr(order), ptr(gmask), K, ptr(out3), n, cout, 1, ptr(fd),
+                            ptr(rd), _lib.stream()))
+    check(L.pcc_conv_fwd(ptr(x), n, cin, ptr(Wd), ptr(wp), ptr(bd), ptr(nbr), ptr(order), ptr(gmask), K, ptr(out32), n, cout, 1,
+                         ptr(fd), ptr(rd), _lib.stream()))
+    again = torch.empty_like(out3)
+    check(L.pcc_conv_fwd_x3(ptr(x), n, cin, ptr(wp3), ptr(bd), ptr(nbr), ptr(order), ptr(gmask), K, ptr(again), n, cout, 1, ptr(fd),
+                            ptr(rd), _lib.stream()))
+    assert torch.equal(out3, again)                                             # deterministic
+    scale = float(ref64.abs().max())
+    e3 = float((out3.cpu().double() - ref64).abs().max()) / scale
+    e32 = float((out32.cpu().double() - ref64).abs().max()) / scale
+    # the fp32 MFMA kernel itself is ~1e-7 .. 1e-6 from float64 here; the split arithmetic must be in the same class
+    assert e3 < 4e-6 and e3 < 4 * e32 + 1e-6, (e3, e32)
+    # natural row order (no execution order, no tile skipping): same bits
+    if ksize == 3:
+        nbr_nat, _, _ = m.kernel_map(m, ksize)
+        nat = torch.empty_like(out3)
+        check(L.pcc_conv_fwd_x3(ptr(x), n, cin, ptr(wp3), ptr(bd), ptr(nbr_nat), None, None, K, ptr(nat), n, cout, 1, ptr(fd), ptr(rd),
+                                _lib.stream()))
+        assert torch.equal(nat, out3)
+
+
+def test_codec_in_x3_mode_meets_the_oracle_parity_bounds(pcc, oracle_codec):
+    from pcc_amd import sparse as sp
+    model = pcc.synthetic.make_model(0, DEV)
+    model.update()
+    assert not sp.INFER_X3
+    sp.set_infer_x3(True)
+    try:
+        for cfg in (dict(grid=32, radius=15.0, half_width=0.875), dict(grid=64, radius=27.0, half_width=0.6)):
+            pts = pcc.synthetic.sphere_shell(**cfg)
+            qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+            N = pts.shape[0]
+            x = torch.from_numpy(pts).to(DEV)
+
+            def code():
+                Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+                strings, shape, k, coords = model.compress(x, Q)
+                rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+                return strings, shape, k, coords, rec
+            strings, shape, k, coords, rec = code()
+            s2, _, _, _, rec2 = code()
+            assert strings == s2 and torch.equal(rec, rec2)                      # deterministic
+            o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
+            assert shape == o_shape and k == o_k
+            bpp, o_bpp = count_bits(strings) / N, count_bits(o_strings) / N
+            assert abs(bpp - o_bpp) <= 2e-3 * o_bpp + 1e-3, (bpp, o_bpp)
+            o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+            rec = rec.cpu().numpy()
+            flips = voxel_flips(rec, o_rec)
+            assert flips <= max(4, int(2e-3 * N)), flips
+            assert_psnr_parity(pc_metrics(pts, rec), pc_metrics(pts, o_rec), flips, N, ("x3", cfg))
+        # encoder-side and decoder-side latents agree bit for bit in this mode too
+        coords4 = torch.cat([torch.zeros((N, 1), device=DEV, dtype=torch.int32), x[:, :3].to(torch.int32)], dim=1)
+        feats = torch.cat([torch.ones((N, 1), device=DEV), x[:, 3:6]], dim=1)
+        inp = pcc.SparseTensor(feats, coordinate_map=pcc.CoordMap(coords4, 1, nbatch=1))
+        Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+        em = model.entropy_model
+        y, _, _ = model.g_a(inp, Q)
+        _, strings, shape = em.compress(y)
+        y_hat_enc, _, _ = em(y)
+        c8 = pcc.CoordMap(y.C, 8, nbatch=1)
+        y_hat_dec, _ = em.decompress([c8, c8.down().down()], strings, shape)
+        idx = y_hat_dec.map.lookup(y.C).long()
+        assert torch.equal(y_hat_dec.F[idx], y_hat_enc.F)
+    finally:
+        sp.set_infer_x3(False)
