@@ -355,7 +355,7 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     n_out = out_map.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
     bf16 = INFER_BF16 and cin % 64 == 0 and x_feats.shape[0] * cin * 2 < 0xFFFFF000
-    x3 = (INFER_X3 and not bf16 and ((cout + 31) // 32 * 32) % 64 == 0 and x_feats.shape[0] * cin * 4 < 0xFFFFF000
+    x3 = (INFER_X3 and not bf16 and cin % 32 == 0 and ((cout + 31) // 32 * 32) % 64 == 0 and x_feats.shape[0] * cin * 4 < 0xFFFFF000
           and (nbr is None or n_out * K * 4 < 0xFFFFF000))
     prof = PROFILER
     if prof is not None:
