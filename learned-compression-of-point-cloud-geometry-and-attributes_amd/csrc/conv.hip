@@ -1107,12 +1107,17 @@ int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t*
     PCC_REQUIRE((uint64_t)n_in * cin * 4 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB && (uint64_t)K * cin * a.coutp * 6 <= BUF_OOB,
                 "pcc_conv_fwd_x3: operands of 4 GiB and more are not supported");
     hipStream_t st = as_stream(stream);
-    static int bn64 = -1;        // PCC_X3_TILE=64: 64-wide column tiles everywhere (A/B)
-    if (bn64 < 0) { const char* e = getenv("PCC_X3_TILE"); bn64 = (e && atoi(e) == 64) ? 1 : 0; }
+    // Tile shapes, measured on the config-2 frame: with the matrix-pipe time at 3/8 the loop waits for its gathers, so
+    // occupancy decides — the three-plane weight slab makes a 64 x 128 tile 64 KB of LDS (two workgroups per CU) and a
+    // 64 x 64 tile 40 KB (four).  64-wide outputs: 64 x 64 tiles 5.2 ms against 5.75 for 128 x 64 on the 5.16 M-row layers;
+    // 128-wide outputs: 64 x 128 tiles 4.95-5.15 ms against 5.2-5.35 for 64 x 64 (which gathers every row twice).
+    // PCC_X3_TILE=64 | 128 forces 64 x 64 / the wider shapes for A/B runs.
+    static int tile = -1;
+    if (tile < 0) { const char* e = getenv("PCC_X3_TILE"); tile = e ? atoi(e) : 0; }
     const int64_t wgs128 = ((a.n_out + 63) / 64) * (a.coutp / 128);
-    if (a.coutp % 128 == 0 && (wgs128 < 768 || bn64)) return launch_mfma_x3<64, 64, 2, 2>(a, st);
+    if (a.coutp % 128 == 0 && (wgs128 < 768 || tile == 64)) return launch_mfma_x3<64, 64, 2, 2>(a, st);
     if (a.coutp % 128 == 0) return launch_mfma_x3<64, 128, 2, 2>(a, st);
-    if (a.coutp % 64 == 0) return launch_mfma_x3<128, 64, 2, 2>(a, st);
+    if (a.coutp % 64 == 0) return tile == 128 ? launch_mfma_x3<128, 64, 2, 2>(a, st) : launch_mfma_x3<64, 64, 2, 2>(a, st);
     pcc::set_error("pcc_conv_fwd_x3: cout=%d not supported (output width rounded up to 32 must be a multiple of 64)", cout);
     return PCC_ERR_UNSUPPORTED;
 }
