@@ -33,6 +33,22 @@ def set_bf16(enabled):
     BF16 = bool(enabled)
 
 
+# Split-bf16 arithmetic for the fp32 training step (opt-in, PCC_TRAIN_X3=1 / set_x3): forward and backward-data
+# convolutions with fp32 data run their products as six bf16 MFMA terms of an exact three-way split (csrc/conv.hip, X3):
+# fp32-class values at 3/8 of the fp32 MFMA time.  Weight gradients stay on the fp32 kernel.  Ignored where BF16 applies.
+X3 = os.environ.get("PCC_TRAIN_X3", "0") == "1"
+
+
+def set_x3(enabled):
+    global X3
+    X3 = bool(enabled)
+
+
+def _x3_ok(rows, cin, cout, n_out, K, has_nbr):
+    return (X3 and cin % 32 == 0 and ((cout + 31) // 32 * 32) % 64 == 0 and rows * cin * 4 < 0xFFFFF000
+            and (not has_nbr or n_out * K * 4 < 0xFFFFF000))
+
+
 def _packed(w):
     """[K, cin, cout] -> MFMA packing (or None for thin cin)"""
     K, cin, cout = w.shape
@@ -59,6 +75,12 @@ def _launch_conv(feats, w, bias, nbr, order, gmask, n_out):
         x = feats if feats.dtype == torch.bfloat16 else feats.to(torch.bfloat16)
         check(L.pcc_conv_fwd_bf16(ptr(x), feats.shape[0], cin, ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K, ptr(out),
                                   n_out, cout, 0, None, None, _lib.stream()))
+        return out
+    if _x3_ok(feats.shape[0], cin, cout, n_out, K, nbr is not None):
+        wp = torch.empty(L.pcc_conv_packed_elems_x3(K, cin, cout), dtype=torch.bfloat16, device=feats.device)
+        check(L.pcc_conv_pack_weights_x3(ptr(w), K, cin, cout, ptr(wp), _lib.stream()))
+        check(L.pcc_conv_fwd_x3(ptr(feats), feats.shape[0], cin, ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K, ptr(out),
+                                n_out, cout, 0, None, None, _lib.stream()))
         return out
     check(L.pcc_conv_fwd(ptr(feats), feats.shape[0], cin, ptr(w), ptr(_packed(w)), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
                          ptr(out), n_out, cout, 0, None, None, _lib.stream()))

@@ -148,3 +148,29 @@ def test_codec_in_x3_mode_meets_the_oracle_parity_bounds(pcc, oracle_codec):
         assert torch.equal(y_hat_dec.F[idx], y_hat_enc.F)
     finally:
         sp.set_infer_x3(False)
+
+
+def test_training_forward_and_backward_data_in_x3_mode_track_fp32(pcc):
+    """PCC_TRAIN_X3 / autograd.set_x3: the differentiable convolution's forward and input gradient through the split
+    arithmetic agree with the fp32 kernels to fp32 rounding; the weight gradient (fp32 kernel in both modes) is identical"""
+    from pcc_amd import autograd as ag
+    torch.manual_seed(5)
+    c = shell()
+    n = c.shape[0]
+    m = pcc.CoordMap(torch.from_numpy(c).to(DEV), 1)
+    layer = pcc.MinkowskiConvolution(128, 128, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
+    x = torch.randn(n, 128, device=DEV, requires_grad=True)
+    g = torch.randn(n, 128, device=DEV)
+    res = {}
+    for mode in (False, True):
+        ag.set_x3(mode)
+        try:
+            out = layer(pcc.SparseTensor(x, coordinate_map=m)).F
+            dx, dw = torch.autograd.grad(out, [x, layer.kernel], g)
+        finally:
+            ag.set_x3(False)
+        res[mode] = (out.detach(), dx, dw)
+    for a, b in zip(res[False][:2], res[True][:2]):
+        assert float((a - b).abs().max()) <= 4e-6 * float(a.abs().max())
+        assert not torch.equal(a, b)                                       # the mode really ran
+    assert torch.equal(res[False][2], res[True][2])
