@@ -330,6 +330,155 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(const WgradArgs a)
 #endif
 }
 
+// Slice kernel for the 64-channel class (the default for K = 27): what bounds these shapes is the byte rate of their
+// gathers — every (X row, dY row) pair is 512 B for 8 k FLOP, twice the forward convolution's bytes per FLOP, and the
+// measured rates (47-57 TFLOP/s) are the forward kernel's gather rate divided by two — so the tiling is chosen to move
+// fewer bytes WITHOUT idling waves (the quad kernel above moved fewer bytes and idled them):
+//   * a workgroup owns the nine offsets of one dz plane and every SPLIT-th group of 32 output rows; the group's dY rows are
+//     staged ONCE and reused by every offset of the plane that occurs in the group (about four of nine on a surface):
+//     8 + 8 L KB per L offset-steps instead of 16 L;
+//   * every wave works in every step: wave (m, n) owns the 32 x 32 tile (m, n) of the 64 x 64 block and keeps one
+//     accumulator per offset of the plane (9 x 16 registers); a step = one (group, offset) = 16 MFMAs per wave;
+//   * double-buffered images, the forward kernel's loop shape: the gathers of step s + 1 are issued before the MFMAs of
+//     step s, the indices of step s + 2 are fetched beside them, one barrier per step.
+template <int O>
+__global__ __launch_bounds__(256) void conv_wgrad_slice_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                 // [2 bufs][2 chunks][32 rows][32 ch]
+    float* Ys = smem + 2 * 2048;      // [2 bufs][2 chunks][32 rows][32 co]
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    const int SPLIT = a.split;
+    const int set = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
+    const int k0 = set * O;
+    const uint32_t set_mask = ((1u << O) - 1u) << k0;
+    const int cbi = a.cin / 32, cbo = a.cout / 32;
+    const int tm = wave_u >> 1, tn = wave_u & 1;                  // my 32 x 32 tile of W[k]
+    const bool tile_live = tm < cbi && tn < cbo;
+    const int cw = wave_u & 1, rh = wave_u >> 1;                  // my DMA role: chunk cw, rows 16 rh .. 16 rh + 15
+
+    f32x16 acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[o][i] = 0.0f;
+
+    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 4), WG_FLAGS);
+    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(uint32_t)(a.n_out * a.cout * 4), WG_FLAGS);
+    const int64_t ng = (a.n_out + 31) >> 5;
+    const int slot = lane & 7, rsub = lane >> 3;
+
+    // ---- step iterator: (group, offset) pairs of my groups, groups ascending, offsets ascending inside a group --------
+    int64_t gb = (int64_t)s - 64 * (int64_t)SPLIT;
+    unsigned long long glive = 0ull;
+    uint32_t gml = 0u;
+    int64_t it_g = -1;            // group of the pending offsets
+    uint32_t it_rem = 0u;         // offsets of it_g not handed out yet
+    int it_ysel = 1;              // dY buffer of it_g (toggles per group)
+    struct Step { int64_t g; int o; int ysel; bool first; bool valid; };
+    auto next_step = [&]() -> Step {
+        Step st;
+        st.first = false;
+        if (it_rem == 0u) {
+            while (!glive) {
+                gb += 64 * (int64_t)SPLIT;
+                if (gb >= ng) { st.g = -1; st.o = k0; st.ysel = 0; st.valid = false; return st; }
+                const int64_t gmine = gb + (int64_t)lane * SPLIT;
+                gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
+                glive = __ballot((gml & set_mask) != 0u);
+            }
+            const int bit = __ffsll(glive) - 1;
+            glive &= glive - 1;
+            it_g = gb + (int64_t)bit * SPLIT;
+            it_rem = (uint32_t)__shfl((int)gml, bit, 64) & set_mask;
+            it_ysel ^= 1;
+            st.first = true;
+        }
+        st.g = it_g;
+        st.o = __builtin_ctz(it_rem);
+        it_rem &= it_rem - 1u;
+        st.ysel = it_ysel;
+        st.valid = true;
+        return st;
+    };
+    // indices of a step's rows (my two rows of the X image, and of the dY image when the step opens a group)
+    auto load_idx = [&](const Step& st, int (&idx)[2], int (&yrow)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int64_t pos = st.g * 32 + 16 * rh + 8 * i + rsub;
+            const bool ok = st.valid && pos < a.n_out;
+            idx[i] = ok ? a.nbr[pos * a.K + st.o] : -1;
+            yrow[i] = (ok && st.first) ? (int)(a.order ? a.order[pos] : pos) : -1;
+        }
+    };
+    auto issue = [&](const Step& st, int xbuf, const int (&idx)[2], const int (&yrow)[2]) {
+        if (!st.valid) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t vo = (idx[i] >= 0 && cw < cbi) ? (uint32_t)idx[i] * (uint32_t)(a.cin * 4) + (uint32_t)(cw * 128 + slot * 16) : WG_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(Xs + xbuf * 2048 + cw * 1024 + (16 * rh + 8 * i) * 32), 16, vo, 0, 0, 0);
+        }
+        if (st.first) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const uint32_t vo = (yrow[i] >= 0 && cw < cbo) ? (uint32_t)yrow[i] * (uint32_t)(a.cout * 4) + (uint32_t)(cw * 128 + slot * 16) : WG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Ys + st.ysel * 2048 + cw * 1024 + (16 * rh + 8 * i) * 32), 16, vo, 0, 0, 0);
+            }
+        }
+    };
+
+    int idx1[2], yrow1[2], idx2[2], yrow2[2];
+    Step s0 = next_step();
+    load_idx(s0, idx1, yrow1);
+    issue(s0, 0, idx1, yrow1);                 // (waits for its own index loads)
+    Step s1 = next_step();
+    load_idx(s1, idx1, yrow1);
+    __syncthreads();
+    int xbuf = 0;
+    while (s0.valid) {
+        issue(s1, xbuf ^ 1, idx1, yrow1);
+        Step s2 = next_step();
+        load_idx(s2, idx2, yrow2);
+        if (tile_live) {
+            const float* Ab = Xs + xbuf * 2048 + tm * 1024 + h * 32 + r;
+            const float* Bb = Ys + s0.ysel * 2048 + tn * 1024 + h * 32 + r;
+            const int oi = s0.o - k0;
+#define PCC_WG_CASE(I)                                                                                              \
+    case I: {                                                                                                       \
+        _Pragma("unroll") for (int kp = 0; kp < 16; ++kp)                                                           \
+            acc[I < O ? I : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[kp * 64], Bb[kp * 64], acc[I < O ? I : 0], 0, 0, 0); \
+    } break;
+            switch (oi) {
+                PCC_WG_CASE(0) PCC_WG_CASE(1) PCC_WG_CASE(2) PCC_WG_CASE(3) PCC_WG_CASE(4)
+                PCC_WG_CASE(5) PCC_WG_CASE(6) PCC_WG_CASE(7) PCC_WG_CASE(8)
+                default: break;
+            }
+#undef PCC_WG_CASE
+        }
+        __syncthreads();                       // vmcnt(0): step s1's images and step s2's indices have landed; s0's images are free
+        s0 = s1;
+        s1 = s2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { idx1[i] = idx2[i]; yrow1[i] = yrow2[i]; }
+        xbuf ^= 1;
+    }
+
+    if (!tile_live) return;
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        float* P = a.partial + ((int64_t)s * a.K + (k0 + o)) * a.cin * a.cout;
+        const int co = tn * 32 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            P[(int64_t)ci * a.cout + co] = acc[o][reg];
+        }
+    }
+#endif
+}
+
 // bf16 operands (pcc_conv_wgrad_bf16; cin, cout multiples of 64): X and dY are bf16, products accumulate in fp32 on
 // v_mfma_f32_32x32x16_bf16.  The GEMM's K dimension is the ROWS, but the LDS images are [row][64 channels]
 // (128-B rows, what the 16-B-per-lane LDS-DMA produces), so a lane's 8 consecutive k-values of one channel sit
@@ -568,8 +717,22 @@ static inline bool wgrad_quad(int cin, int cout, int K) {
     if (on < 0) { const char* e = getenv("PCC_WGRAD_QUAD"); on = (e && e[0] == '1') ? 1 : 0; }
     return on && wgrad_rowsplit(cin, cout) && K == 27;
 }
+// slice kernel (nine offsets = one dz plane per workgroup, dY rows staged once per group): the default for 64-channel-class
+// blocks of a 27-offset kernel; PCC_WGRAD_SLICE=0 keeps the one-offset kernel for A/B runs
+static inline bool wgrad_slice(int cin, int cout, int K) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PCC_WGRAD_SLICE"); on = (e && e[0] == '0') ? 0 : 1; }
+    return on && wgrad_rowsplit(cin, cout) && K == 27;
+}
+constexpr int WG_SPLIT_SLICE_MAX = 256;
+static inline int wgrad_slice_splits(int64_t n_out) {      // three workgroup sets only: more splits to fill 256 CUs x 4
+    const int64_t want = ((n_out + 31) / 32) / 24;
+    return (int)(want < 8 ? 8 : (want > WG_SPLIT_SLICE_MAX ? WG_SPLIT_SLICE_MAX : want));
+}
 static inline int wgrad_partials(int cin, int cout, int split, int K) {
-    return !wgrad_mfma(cin, cout) ? WG_SPLIT_THIN : split * ((wgrad_rowsplit(cin, cout) && !wgrad_quad(cin, cout, K)) ? 4 : 1);
+    if (!wgrad_mfma(cin, cout)) return WG_SPLIT_THIN;
+    if (wgrad_slice(cin, cout, K) || wgrad_quad(cin, cout, K)) return split;
+    return split * (wgrad_rowsplit(cin, cout) ? 4 : 1);
 }
 
 int64_t pcc_conv_wgrad_scratch_elems(int32_t K, int32_t cin, int32_t cout) {
@@ -596,7 +759,10 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
                     "pcc_conv_wgrad: operands of 4 GiB and more are not supported yet");
         PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
                     "pcc_conv_wgrad: fin and dy must be 16-byte aligned (16-byte LDS-DMA loads)");
-        if (wgrad_quad(cin, cout, K)) {
+        if (wgrad_slice(cin, cout, K)) {
+            a.split = wgrad_slice_splits(n_out);
+            hipLaunchKernelGGL(conv_wgrad_slice_kernel<9>, dim3((unsigned)(3 * a.split)), dim3(256), 8 * 1024 * sizeof(float), st, a);
+        } else if (wgrad_quad(cin, cout, K)) {
             hipLaunchKernelGGL(conv_wgrad_quad_kernel, dim3((unsigned)(((K + 3) / 4) * a.split)), dim3(256), 10 * 1024 * sizeof(float), st, a);
         } else {
             const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
