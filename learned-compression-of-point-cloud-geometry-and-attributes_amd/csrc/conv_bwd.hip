@@ -341,19 +341,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(const WgradArgs a)
 //     accumulator per offset of the plane (9 x 16 registers); a step = one (group, offset) = 16 MFMAs per wave;
 //   * double-buffered images, the forward kernel's loop shape: the gathers of step s + 1 are issued before the MFMAs of
 //     step s, the indices of step s + 2 are fetched beside them, one barrier per step.
-template <int O>
+// AHEAD = how many steps the gathers run in front of the MFMAs: 1 = two images per operand and __syncthreads() per step;
+// 2 = three images, the step's wait is a counted s_waitcnt vmcnt(4) (everything but the newest four memory operations — the
+// X gathers of the step after next and the index loads of the one after that, two each at least — has landed) + a bare
+// s_barrier, so two steps' gathers are in flight per workgroup.
+template <int O, int AHEAD>
 __global__ __launch_bounds__(256) void conv_wgrad_slice_kernel(const WgradArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int NB = AHEAD + 1;     // images per operand
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                 // [2 bufs][2 chunks][32 rows][32 ch]
-    float* Ys = smem + 2 * 2048;      // [2 bufs][2 chunks][32 rows][32 co]
+    float* Xs = smem;                 // [NB][2 chunks][32 rows][32 ch]
+    float* Ys = smem + NB * 2048;     // [NB][2 chunks][32 rows][32 co]
     const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);
     const int SPLIT = a.split;
     const int set = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
     const int k0 = set * O;
-    const uint32_t set_mask = ((1u << O) - 1u) << k0;
+    const uint32_t set_mask = (((1u << O) - 1u) << k0) & 0x7FFFFFFu;
     const int cbi = a.cin / 32, cbo = a.cout / 32;
     const int tm = wave_u >> 1, tn = wave_u & 1;                  // my 32 x 32 tile of W[k]
     const bool tile_live = tm < cbi && tn < cbo;
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_slice_kernel(const WgradArgs a
     uint32_t gml = 0u;
     int64_t it_g = -1;            // group of the pending offsets
     uint32_t it_rem = 0u;         // offsets of it_g not handed out yet
-    int it_ysel = 1;              // dY buffer of it_g (toggles per group)
+    int it_ysel = NB - 1;         // dY image of it_g (advances per group)
     struct Step { int64_t g; int o; int ysel; bool first; bool valid; };
     auto next_step = [&]() -> Step {
         Step st;
@@ -393,7 +398,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_slice_kernel(const WgradArgs a
             glive &= glive - 1;
             it_g = gb + (int64_t)bit * SPLIT;
             it_rem = (uint32_t)__shfl((int)gml, bit, 64) & set_mask;
-            it_ysel ^= 1;
+            it_ysel = (it_ysel + 1 == NB) ? 0 : it_ysel + 1;
             st.first = true;
         }
         st.g = it_g;
@@ -403,14 +408,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_slice_kernel(const WgradArgs a
         st.valid = true;
         return st;
     };
-    // indices of a step's rows (my two rows of the X image, and of the dY image when the step opens a group)
+    // indices of a step's rows (my two rows of the X image, and of the dY image when the step opens a group).  A valid
+    // step always issues its two index loads (clamped addresses), whatever the lanes' rows: the counted wait relies on it.
     auto load_idx = [&](const Step& st, int (&idx)[2], int (&yrow)[2]) {
+        if (!st.valid) {
+            idx[0] = idx[1] = yrow[0] = yrow[1] = -1;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int64_t pos = st.g * 32 + 16 * rh + 8 * i + rsub;
-            const bool ok = st.valid && pos < a.n_out;
-            idx[i] = ok ? a.nbr[pos * a.K + st.o] : -1;
-            yrow[i] = (ok && st.first) ? (int)(a.order ? a.order[pos] : pos) : -1;
+            const bool ok = pos < a.n_out;
+            const int64_t pc = ok ? pos : a.n_out - 1;
+            const int v = a.nbr[pc * a.K + st.o];
+            idx[i] = ok ? v : -1;
+            yrow[i] = -1;
+            if (st.first) {
+                const int yr = a.order ? a.order[pc] : (int)pc;
+                yrow[i] = ok ? yr : -1;
+            }
         }
     };
     auto issue = [&](const Step& st, int xbuf, const int (&idx)[2], const int (&yrow)[2]) {
@@ -428,46 +444,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_slice_kernel(const WgradArgs a
             }
         }
     };
-
-    int idx1[2], yrow1[2], idx2[2], yrow2[2];
-    Step s0 = next_step();
-    load_idx(s0, idx1, yrow1);
-    issue(s0, 0, idx1, yrow1);                 // (waits for its own index loads)
-    Step s1 = next_step();
-    load_idx(s1, idx1, yrow1);
-    __syncthreads();
-    int xbuf = 0;
-    while (s0.valid) {
-        issue(s1, xbuf ^ 1, idx1, yrow1);
-        Step s2 = next_step();
-        load_idx(s2, idx2, yrow2);
-        if (tile_live) {
-            const float* Ab = Xs + xbuf * 2048 + tm * 1024 + h * 32 + r;
-            const float* Bb = Ys + s0.ysel * 2048 + tn * 1024 + h * 32 + r;
-            const int oi = s0.o - k0;
+    auto compute = [&](const Step& st, int xbuf) {
+        if (!tile_live) return;
+        const float* Ab = Xs + xbuf * 2048 + tm * 1024 + h * 32 + r;
+        const float* Bb = Ys + st.ysel * 2048 + tn * 1024 + h * 32 + r;
+        const int oi = st.o - k0;
 #define PCC_WG_CASE(I)                                                                                              \
     case I: {                                                                                                       \
         _Pragma("unroll") for (int kp = 0; kp < 16; ++kp)                                                           \
             acc[I < O ? I : 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ab[kp * 64], Bb[kp * 64], acc[I < O ? I : 0], 0, 0, 0); \
     } break;
-            switch (oi) {
-                PCC_WG_CASE(0) PCC_WG_CASE(1) PCC_WG_CASE(2) PCC_WG_CASE(3) PCC_WG_CASE(4)
-                PCC_WG_CASE(5) PCC_WG_CASE(6) PCC_WG_CASE(7) PCC_WG_CASE(8)
-                default: break;
-            }
-#undef PCC_WG_CASE
+        switch (oi) {
+            PCC_WG_CASE(0) PCC_WG_CASE(1) PCC_WG_CASE(2) PCC_WG_CASE(3) PCC_WG_CASE(4)
+            PCC_WG_CASE(5) PCC_WG_CASE(6) PCC_WG_CASE(7) PCC_WG_CASE(8)
+            default: break;
         }
-        __syncthreads();                       // vmcnt(0): step s1's images and step s2's indices have landed; s0's images are free
-        s0 = s1;
-        s1 = s2;
+#undef PCC_WG_CASE
+    };
+
+    int idxA[2], yrowA[2], idxB[2], yrowB[2];
+    if constexpr (AHEAD == 1) {
+        Step s0 = next_step();
+        load_idx(s0, idxA, yrowA);
+        issue(s0, 0, idxA, yrowA);                 // (waits for its own index loads)
+        Step s1 = next_step();
+        load_idx(s1, idxA, yrowA);
+        __syncthreads();
+        int xbuf = 0;
+        while (s0.valid) {
+            issue(s1, xbuf ^ 1, idxA, yrowA);
+            Step s2 = next_step();
+            load_idx(s2, idxB, yrowB);
+            compute(s0, xbuf);
+            __syncthreads();                       // vmcnt(0): step s1's images and step s2's indices have landed; s0's images are free
+            s0 = s1;
+            s1 = s2;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { idx1[i] = idx2[i]; yrow1[i] = yrow2[i]; }
-        xbuf ^= 1;
+            for (int i = 0; i < 2; ++i) { idxA[i] = idxB[i]; yrowA[i] = yrowB[i]; }
+            xbuf ^= 1;
+        }
+    } else {
+        Step s0 = next_step();
+        load_idx(s0, idxA, yrowA);
+        issue(s0, 0, idxA, yrowA);
+        Step s1 = next_step();
+        load_idx(s1, idxA, yrowA);
+        issue(s1, 1, idxA, yrowA);
+        Step s2 = next_step();
+        load_idx(s2, idxA, yrowA);                 // stays in registers until its gathers are issued in the loop
+        int xb0 = 0;                               // image of s0; s1 = xb0 + 1, s2 = xb0 + 2 (mod 3)
+        while (s0.valid) {
+            Step s3 = next_step();
+            load_idx(s3, idxB, yrowB);
+            // all but the newest four memory operations have landed: newer than s0's gathers are s2's index loads (older
+            // than the four), s1's gathers (>= 2) and s3's index loads (2)
+            if (s1.valid && s3.valid) __builtin_amdgcn_s_waitcnt(0x0074);
+            else __builtin_amdgcn_s_waitcnt(0x0070);
+            __builtin_amdgcn_s_barrier();
+            issue(s2, xb0 == 0 ? 2 : xb0 - 1, idxA, yrowA);
+            compute(s0, xb0);
+            s0 = s1;
+            s1 = s2;
+            s2 = s3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { idxA[i] = idxB[i]; yrowA[i] = yrowB[i]; }
+            xb0 = (xb0 == 2) ? 0 : xb0 + 1;
+        }
     }
 
     if (!tile_live) return;
 #pragma unroll
     for (int o = 0; o < O; ++o) {
+        if (k0 + o >= a.K) break;
         float* P = a.partial + ((int64_t)s * a.K + (k0 + o)) * a.cin * a.cout;
         const int co = tn * 32 + r;
 #pragma unroll
@@ -760,8 +808,23 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
         PCC_REQUIRE(((reinterpret_cast<uintptr_t>(fin) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0,
                     "pcc_conv_wgrad: fin and dy must be 16-byte aligned (16-byte LDS-DMA loads)");
         if (wgrad_slice(cin, cout, K)) {
+            static int O = -1;       // PCC_WGRAD_SLICE_O=3|5|9: offsets per workgroup (A/B; accumulators = 16 O registers per lane)
+            if (O < 0) { const char* e = getenv("PCC_WGRAD_SLICE_O"); O = e ? atoi(e) : 5; }
             a.split = wgrad_slice_splits(n_out);
-            hipLaunchKernelGGL(conv_wgrad_slice_kernel<9>, dim3((unsigned)(3 * a.split)), dim3(256), 8 * 1024 * sizeof(float), st, a);
+            static int ahead = -1;   // PCC_WGRAD_AHEAD=1|2: prefetch distance of the gathers (A/B)
+            if (ahead < 0) { const char* e = getenv("PCC_WGRAD_AHEAD"); ahead = (e && e[0] == '1') ? 1 : 2; }
+#define PCC_SLICE(OO)                                                                                                              \
+    do {                                                                                                                           \
+        const dim3 grid((unsigned)(((27 + OO - 1) / OO) * a.split));                                                               \
+        if (ahead == 1) hipLaunchKernelGGL((conv_wgrad_slice_kernel<OO, 1>), grid, dim3(256), 2 * 2 * 2048 * sizeof(float), st, a); \
+        else hipLaunchKernelGGL((conv_wgrad_slice_kernel<OO, 2>), grid, dim3(256), 2 * 3 * 2048 * sizeof(float), st, a);            \
+    } while (0)
+            if (O == 3) PCC_SLICE(3);
+            else if (O == 4) PCC_SLICE(4);
+            else if (O == 6) PCC_SLICE(6);
+            else if (O == 9) PCC_SLICE(9);
+            else PCC_SLICE(5);
+#undef PCC_SLICE
         } else if (wgrad_quad(cin, cout, K)) {
             hipLaunchKernelGGL(conv_wgrad_quad_kernel, dim3((unsigned)(((K + 3) / 4) * a.split)), dim3(256), 10 * 1024 * sizeof(float), st, a);
         } else {
