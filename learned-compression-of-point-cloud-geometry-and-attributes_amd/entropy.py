@@ -377,6 +377,35 @@ class EntropyBottleneck(_EntropyModelBase):
         check(_lib.lib().pcc_eb_dequantize(ptr(sym), n, c, ptr(self.medians().to(device)), ptr(zhat), _lib.stream()))
         return zhat
 
+    def decompress_features_async(self, strings, n, device):
+        """Start the (host, serial) range decode of z on a worker thread — it needs nothing from the GPU — and return a
+        function that joins it and dequantises: in between the caller builds the coordinate sets and kernel maps that
+        depend on coordinates only."""
+        import threading
+        cdf, cdf_len, off = self.tables()
+        c = self.channels
+        box = {}
+
+        def work():
+            try:
+                box["sym"] = _rans_decode(strings[0], np.repeat(np.arange(c, dtype=np.int32), n), cdf, cdf_len, off)
+            except BaseException as e:      # re-raised on the caller's thread
+                box["err"] = e
+
+        th = threading.Thread(target=work, name="pcc-rans-decode-z")
+        th.start()
+
+        def finish():
+            th.join()
+            if "err" in box:
+                raise box["err"]
+            sym = torch.from_numpy(box["sym"].reshape(c, n)).to(device)
+            zhat = torch.empty((n, c), dtype=torch.float32, device=device)
+            check(_lib.lib().pcc_eb_dequantize(ptr(sym), n, c, ptr(self.medians().to(device)), ptr(zhat), _lib.stream()))
+            return zhat
+
+        return finish
+
     def decompress(self, strings, size):
         n = int(size[0])
         return self.decompress_features(strings, n, self.quantiles.device).t().unsqueeze(0)

@@ -121,8 +121,16 @@ class MeanScaleHyperprior_Map(nn.Module):
         y_sorted = CoordMap(y_map.coords.index_select(0, y_map.sort_permutation().long()), 8, nbatch=y_map._nbatch)
         z_sorted = CoordMap(z_map.coords.index_select(0, z_map.sort_permutation().long()), 32, nbatch=z_map._nbatch)
         y_strings, z_strings = strings
-        z_hat_f = self.entropy_bottleneck.decompress_features(z_strings, int(shape[0]), z_sorted.device)
-        z_hat = SparseTensor(z_hat_f, coordinate_map=z_sorted)
+        # the z stream needs nothing from the GPU: its host decode runs while the GPU builds what depends on coordinates
+        # only — the tables and kernel maps of h_s (z -> 16 -> 8, evaluated at y) and of the first h_q layer
+        finish_z = self.entropy_bottleneck.decompress_features_async(z_strings, int(shape[0]), z_sorted.device)
+        z_sorted.ordered_kernel_map(z_sorted, 3)
+        z16 = z_sorted.up(2)
+        z_sorted.ordered_kernel_map(z16, 2, True)
+        z16.ordered_kernel_map(z16, 3)
+        z16.ordered_kernel_map(z16.up(2), 2, True)
+        z16.up(2).ordered_kernel_map(y_sorted, 3)
+        z_hat = SparseTensor(finish_z(), coordinate_map=z_sorted)
         # h_s first: its output (scales | means) is what the serial rANS decode of y is waiting for.  While
         # the host decodes (~15 ms for 2.5 M symbols) the GPU runs everything that does not need y: h_q
         # and the coordinate sets / kernel maps of the first synthesis stage.
