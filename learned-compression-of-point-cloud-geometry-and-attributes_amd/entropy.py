@@ -526,13 +526,14 @@ class GaussianConditional(_EntropyModelBase):
         table = self.scale_table.to(dev).contiguous()
         check(_lib.lib().pcc_gc_encode_prep_packed(None, ptr(params.contiguous()), n, c, ptr(table), table.numel(), None, None,
                                                    ptr(idx_dev), None, _lib.stream()))
-        idx_host = _to_host(idx_dev, "gc_idx8")
+        idx_host, idx_ev = _to_host_async(idx_dev, "gc_idx8")      # the worker waits for the copy; this thread goes on enqueueing h_q
         sym_host = _pinned("gc_sym16", cn, torch.int16)
         cdf, cdf_len, off = self.tables()
         box = {}
 
         def work():
             try:
+                idx_ev.synchronize()
                 box["fits"] = _rans_decode_packed(strings[0], idx_host, cdf, cdf_len, off, sym_host.numpy())
                 if not box["fits"]:                                              # a symbol beyond int16: int32 planes
                     box["sym"] = _rans_decode(strings[0], idx_host.astype(np.int32), cdf, cdf_len, off)
