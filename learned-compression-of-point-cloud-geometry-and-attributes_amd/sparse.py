@@ -40,20 +40,32 @@ _COUNT_BUFS = {}
 
 
 def _host_count():
-    """A page-locked int64 the device writes a row count into directly (zero-copy): reading it back takes a stream
-    synchronisation instead of a device-to-host copy plus one.  One per host thread (worker threads code frames
-    concurrently)."""
+    """A page-locked int64 the device writes a row count into directly (zero-copy).  The count kernel (the scan of the
+    block sums) runs BEFORE the kernels that move the rows, so the host — which polls the word instead of synchronising
+    the stream — learns the count while those are still running and goes on allocating and enqueueing.  One word per
+    host thread (worker threads code frames concurrently); armed with -1 before every use."""
     import threading
     key = threading.get_ident()
-    buf = _COUNT_BUFS.get(key)
-    if buf is None:
-        buf = _COUNT_BUFS[key] = torch.zeros(1, dtype=torch.int64, pin_memory=True)
-    return buf
+    hit = _COUNT_BUFS.get(key)
+    if hit is None:
+        buf = torch.zeros(1, dtype=torch.int64, pin_memory=True)
+        hit = _COUNT_BUFS[key] = (buf, buf.numpy())
+    hit[1][0] = -1
+    return hit[0]
 
 
 def _read_count(buf, device):
-    torch.cuda.current_stream(device).synchronize()
-    return int(buf[0])
+    import time
+    arr = _COUNT_BUFS[__import__("threading").get_ident()][1]
+    deadline = time.perf_counter() + 2e-3
+    while arr[0] < 0:
+        if time.perf_counter() > deadline:        # not visible yet (or the stream is behind): fall back to a real wait
+            torch.cuda.current_stream(device).synchronize()
+            break
+    n = int(arr[0])
+    if n < 0:
+        raise RuntimeError("libpcc_hip: the row count was never written (kernel failure?)")
+    return n
 
 
 class CoordMap:
