@@ -50,9 +50,11 @@ def kernel_source_sha256():
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "learned-compression-of-point-cloud-geometry-and-attributes_amd", "csrc")
-    for name in ("conv.hip", "common.h", "Makefile"):
+    for name in ("conv.hip", "common.h"):
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
+    with open(os.path.join(base, "Makefile")) as f:          # the compiler flags, not the list of sources
+        h.update("".join(line for line in f if line.startswith("HIPFLAGS")).encode())
     return h.hexdigest()
 
 

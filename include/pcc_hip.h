@@ -153,6 +153,16 @@ int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint
                       const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                       int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
 
+/* Training-path epilogue of a convolution as its own operator (the inference path fuses it into pcc_conv_fwd):
+ *   forward   out = act(film ? c * beta + gamma : c) + (residual ? residual : 0)     (blocks.py:37-40,49-52)
+ *   backward  du = dout * act'(u);  dc = film ? du * beta : du;  dfilm = [du * c | du]   (d residual = dout)
+ * c / out / dout / dc [n, channels], film / dfilm [n, 2 * channels] (beta | gamma); channels % 4 == 0, 16-byte aligned.
+ * Same operation order as the torch ops they replace (mul, add, act, add): identical values and gradients. */
+int pcc_epilogue_fwd(const float* c, const float* film, const float* residual, int64_t n, int32_t channels, int32_t act,
+                     float* out, void* stream);
+int pcc_epilogue_bwd(const float* dout, const float* c, const float* film, int64_t n, int32_t channels, int32_t act,
+                     float* dc, float* dfilm, void* stream);
+
 /* Split-bf16 arithmetic on fp32 data (opt-in; the default convolution multiplies in fp32): every fp32 operand is
  * the exact sum of three bf16 numbers; the weights are pre-split into three planes (pcc_conv_pack_weights_x3,
  * pcc_conv_packed_elems_x3 bf16 elements), the gathered fp32 rows are split in registers, and the six products

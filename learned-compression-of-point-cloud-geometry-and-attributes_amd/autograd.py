@@ -218,6 +218,49 @@ class SparseConvFn(torch.autograd.Function):
         return d_feats, d_kernel, d_bias, None, None, None, None, None
 
 
+class EpilogueFn(torch.autograd.Function):
+    """out = act(c * beta + gamma) + residual as ONE kernel forward and ONE backward (csrc/epilogue.hip) — the terms the
+    inference path fuses into the convolution's epilogue; same operation order, hence the same values and gradients, as
+    the chain of torch ops this replaces"""
+
+    @staticmethod
+    def forward(ctx, c, film, residual, act):
+        c = c.contiguous()
+        film = None if film is None else film.contiguous()
+        residual = None if residual is None else residual.contiguous()
+        n, ch = c.shape
+        out = torch.empty_like(c)
+        check(_lib.lib().pcc_epilogue_fwd(ptr(c), ptr(film), ptr(residual), n, ch, act, ptr(out), _lib.stream()))
+        ctx.save_for_backward(c, film)
+        ctx.act = act
+        ctx.has_res = residual is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        c, film = ctx.saved_tensors
+        dout = dout.contiguous()
+        n, ch = c.shape
+        dc = torch.empty_like(c)
+        dfilm = None if film is None else torch.empty_like(film)
+        check(_lib.lib().pcc_epilogue_bwd(ptr(dout), ptr(c), ptr(film), n, ch, ctx.act, ptr(dc), ptr(dfilm), _lib.stream()))
+        return dc, dfilm, (dout if ctx.has_res else None), None
+
+
+def epilogue_train(c, film, residual, act):
+    """differentiable epilogue; falls back to torch ops for shapes the kernel does not take (channels % 4 != 0)"""
+    ch = c.shape[1]
+    if ch % 4 == 0 and (film is None or film.shape[1] == 2 * ch):
+        return EpilogueFn.apply(c, film, residual, act)
+    if film is not None:
+        c = c * film[:, :ch] + film[:, ch:]
+    if act == 1:
+        c = torch.relu(c)
+    elif act == 2:
+        c = torch.nn.functional.leaky_relu(c, 0.01)
+    return c if residual is None else c + residual
+
+
 def conv_train(x_feats, in_map, out_map, layer, ksize, transposed, out_channels=None):
     """differentiable out = bias + conv(x) on the HIP kernels"""
     return SparseConvFn.apply(x_feats, layer.kernel, layer.bias, in_map, out_map, ksize, transposed, out_channels)

@@ -588,19 +588,12 @@ class _ConvBase(nn.Module):
         if out_map is None:
             out_map = self.output_map(x.map)
         if torch.is_grad_enabled() and (self.kernel.requires_grad or x.F.requires_grad):
-            # training path: the convolution is an autograd node on the HIP kernels, its epilogue plain torch ops
-            # in the order the fused epilogue applies them (bias, FiLM, activation, residual)
-            from .autograd import conv_train
+            # training path: the convolution is an autograd node on the HIP kernels, its epilogue (FiLM, activation,
+            # residual — in the order the fused inference epilogue applies them) a second one (csrc/epilogue.hip)
+            from .autograd import conv_train, epilogue_train
             feats = conv_train(x.F, x.map, out_map, self, self.kernel_size, self.transposed, out_channels)
-            if film is not None:
-                c = feats.shape[1]
-                feats = feats * film[:, :c] + film[:, c:]
-            if act == ACT_RELU:
-                feats = torch.relu(feats)
-            elif act == ACT_LRELU:
-                feats = torch.nn.functional.leaky_relu(feats, 0.01)
-            if residual is not None:
-                feats = feats + residual
+            if film is not None or act != ACT_NONE or residual is not None:
+                feats = epilogue_train(feats, film, residual, act)          # one kernel forward, one backward
             return SparseTensor(feats, coordinate_map=out_map)
         feats = conv_forward(x.F, x.map, out_map, self, self.kernel_size, self.transposed, act, film, residual,
                              out_channels)
