@@ -161,3 +161,29 @@ def test_scalar_weight_gradient_entry_point(pcc, cin, cout):
         ok = nb[:, k] >= 0
         want[k] = X[nb[ok, k]].t() @ G[ok]
     assert close(dw.cpu(), want)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("with_film,with_res", [(True, True), (True, False), (False, True), (False, False)])
+def test_fused_epilogue_equals_the_torch_chain_bitwise(pcc, act, with_film, with_res):
+    """csrc/epilogue.hip: out = act(c * beta + gamma) + residual as one kernel forward and one backward — the same
+    operation order as the torch ops it replaces on the training path, so values AND gradients are bit-identical"""
+    from pcc_amd.autograd import EpilogueFn
+    if act == 0 and not with_film and not with_res:
+        pytest.skip("identity")
+    torch.manual_seed(act * 4 + with_film * 2 + with_res)
+    n, ch = 1000, 64
+    c = torch.randn(n, ch, device=DEV, requires_grad=True)
+    film = torch.randn(n, 2 * ch, device=DEV, requires_grad=True) if with_film else None
+    res = torch.randn(n, ch, device=DEV, requires_grad=True) if with_res else None
+    g = torch.randn(n, ch, device=DEV)
+    u = c * film[:, :ch] + film[:, ch:] if with_film else c
+    v = torch.relu(u) if act == 1 else torch.nn.functional.leaky_relu(u, 0.01) if act == 2 else u
+    want = v + res if with_res else v
+    leaves = [t for t in (c, film, res) if t is not None]
+    want_g = torch.autograd.grad(want, leaves, g)
+    got = EpilogueFn.apply(c, film, res, act)
+    got_g = torch.autograd.grad(got, leaves, g)
+    assert torch.equal(got, want)
+    for a, b in zip(got_g, want_g):
+        assert torch.equal(a, b)
