@@ -8,6 +8,8 @@
 // thread arrival order.  No host synchronisation: all passes are enqueued; a batch that has
 // resolved early turns the remaining passes into no-ops through its `done` word.
 // HBM-bound wavefront-level integer work, no dense contraction.
+#include <stdlib.h>
+
 #include "common.h"
 #include "sort.h"
 
@@ -156,25 +158,79 @@ __global__ __launch_bounds__(256) void coords_to_keys(const int32_t* __restrict_
 }
 
 // ---- execution order of a kernel map's output rows -------------------------------------------
-// key = (27 - popcount) << 27 | 27-bit neighbour mask (32 bits; with spatial blocks the block id goes on top:
-// 64 bits).  Rows with equal masks become adjacent so that 32-row MFMA tiles execute (almost) only offsets
-// every row of the tile has; the heaviest rows come first: tiles are dispatched in key order, so the expensive
-// ones start early and the tail of a launch consists of cheap tiles.
+// Rows are sorted by their 27-bit neighbour mask read with the RAREST offset as the most significant bit, descending: rows
+// with equal masks become adjacent, and where masks are too diverse for that (the sparse sets an untrained decoder keeps:
+// tens of thousands of distinct masks) the rows of a 32-row MFMA tile at least agree on the rare offsets, which are the
+// ones a tile should not have to execute for a single row.  Measured on surface subsets (offline, tools/order_experiment.py):
+// issued / useful MFMA rows 2.27 -> 1.80 at 6.8 neighbours per row, 1.13 -> 1.08 on a full surface, against the previous
+// key (27 - popcount) << 27 | mask; candidate sets (437 distinct masks) are at 1.00 either way.  Descending = rows holding
+// the rare (corner) offsets, the heavy ones, first: tiles are dispatched in key order, so a launch ends on its cheap tiles.
+// With spatial blocks the block id goes on top (64-bit key).
+__global__ __launch_bounds__(256) void mask_bit_counts_kernel(const uint32_t* __restrict__ row_mask, int64_t n,
+                                                              uint32_t* __restrict__ counts) {
+    __shared__ unsigned c[27];
+    if (threadIdx.x < 27) c[threadIdx.x] = 0u;
+    __syncthreads();
+    unsigned mine[27];
+#pragma unroll
+    for (int b = 0; b < 27; ++b) mine[b] = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t m = row_mask[i];
+#pragma unroll
+        for (int b = 0; b < 27; ++b) mine[b] += (m >> b) & 1u;
+    }
+#pragma unroll
+    for (int b = 0; b < 27; ++b) {
+        unsigned v = mine[b];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&c[b], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 27 && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], c[threadIdx.x]);
+}
+
+// bit position of every offset in the sort key: the rarest offset (ties: the lower offset index) takes bit 26
+__device__ __forceinline__ void order_bit_positions(const uint32_t* __restrict__ counts, int* pos_s) {
+    if (threadIdx.x < 27) {
+        const uint32_t mine = counts[threadIdx.x];
+        int rank = 0;
+        for (int b = 0; b < 27; ++b) {
+            const uint32_t o = counts[b];
+            rank += (o < mine || (o == mine && b < (int)threadIdx.x)) ? 1 : 0;
+        }
+        pos_s[threadIdx.x] = 26 - rank;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ uint32_t order_key_of(uint32_t m, const int* pos_s) {
+    uint32_t key = 0u;
+#pragma unroll
+    for (int b = 0; b < 27; ++b) key |= ((m >> b) & 1u) << pos_s[b];
+    return 0x7FFFFFFu - key;                         // descending in the permuted mask
+}
+
 __global__ __launch_bounds__(256) void order_keys32_kernel(const uint32_t* __restrict__ row_mask, int64_t n,
-                                                           uint32_t* __restrict__ keys) {
+                                                           const uint32_t* __restrict__ counts, uint32_t* __restrict__ keys,
+                                                           int legacy) {
+    __shared__ int pos_s[27];
+    order_bit_positions(counts, pos_s);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t m = row_mask[i] & 0x7FFFFFFu;
-    keys[i] = ((uint32_t)(27 - __popc(m)) << 27) | m;
+    keys[i] = legacy ? (((uint32_t)(27 - __popc(m)) << 27) | m) : order_key_of(m, pos_s);      // legacy: round 1's key (A/B)
 }
 
 __global__ __launch_bounds__(256) void order_keys64_kernel(const uint32_t* __restrict__ row_mask,
                                                            const int32_t* __restrict__ coords, int64_t n,
-                                                           int block_log2, int ts, uint64_t* __restrict__ keys) {
+                                                           int block_log2, int ts, const uint32_t* __restrict__ counts,
+                                                           uint64_t* __restrict__ keys) {
+    __shared__ int pos_s[27];
+    order_bit_positions(counts, pos_s);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t m = row_mask[i] & 0x7FFFFFFu;
-    uint64_t key = ((uint64_t)(27 - __popc(m)) << 27) | m;
+    uint64_t key = order_key_of(row_mask[i] & 0x7FFFFFFu, pos_s);
     const int4 c = reinterpret_cast<const int4*>(coords)[i];
     const uint64_t bx = (uint64_t)(((c.y / ts) + 512) >> block_log2) & 0x3FF;
     const uint64_t by = (uint64_t)(((c.z / ts) + 512) >> block_log2) & 0x3FF;
@@ -256,19 +312,25 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     char* keys_b = p; p += align256(n * 8);
     int32_t* vals_x = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
     void* counters = p;
-    const int begin = 0, end = block_log2 >= 0 ? 64 : 32;
+    uint32_t* bit_counts = reinterpret_cast<uint32_t*>(p + radix_sort_counter_bytes(n));       // 27 words in the scratch's 256-byte tail
+    PCC_CHECK_HIP(hipMemsetAsync(bit_counts, 0, 27 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(mask_bit_counts_kernel, dim3(blocks_for(n, 256 * 16, 512)), dim3(256), 0, st, row_mask, n, bit_counts);
+    static int legacy = -1;      // PCC_ORDER_KEY=popcount: round 1's key (27 - popcount) << 27 | mask, for A/B runs
+    if (legacy < 0) { const char* e = getenv("PCC_ORDER_KEY"); legacy = (e && e[0] == 'p') ? 1 : 0; }
+    const int begin = 0, end = block_log2 >= 0 ? 64 : (legacy ? 32 : 27);
     // the sorted values must land in `order`: they end in the b-side when the pass count is odd
     const bool in_b = radix_sort_result_in_b(begin, end);
     int32_t* va = in_b ? vals_x : order;
     int32_t* vb = in_b ? order : vals_x;
     int rc;
     if (block_log2 < 0) {
-        hipLaunchKernelGGL(order_keys32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, n, reinterpret_cast<uint32_t*>(keys_a));
+        hipLaunchKernelGGL(order_keys32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, n, bit_counts,
+                           reinterpret_cast<uint32_t*>(keys_a), legacy);
         rc = radix_sort_pairs_u32(reinterpret_cast<uint32_t*>(keys_a), reinterpret_cast<uint32_t*>(keys_b), va, vb, true, n, begin, end,
                                   counters, st);
     } else {
         hipLaunchKernelGGL(order_keys64_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, coords, n, block_log2, tensor_stride,
-                           reinterpret_cast<uint64_t*>(keys_a));
+                           bit_counts, reinterpret_cast<uint64_t*>(keys_a));
         rc = radix_sort_pairs_u64(reinterpret_cast<uint64_t*>(keys_a), reinterpret_cast<uint64_t*>(keys_b), va, vb, true, n, begin, end,
                                   counters, st);
     }

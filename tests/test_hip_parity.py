@@ -112,6 +112,18 @@ def _nbr_as_coords(nbr, in_coords):
     return out
 
 
+def order_key(masks):
+    """the execution-order key of csrc/select.hip: the 27-bit neighbour mask read with the rarest offset as the most
+    significant bit (ties: lower offset first), descending"""
+    masks = np.asarray(masks, dtype=np.int64) & 0x7FFFFFF
+    cnt = np.array([int(((masks >> b) & 1).sum()) for b in range(27)])
+    pos = [26 - sum(1 for o in range(27) if cnt[o] < cnt[b] or (cnt[o] == cnt[b] and o < b)) for b in range(27)]
+    key = np.zeros(masks.shape[0], dtype=np.int64)
+    for b in range(27):
+        key |= ((masks >> b) & 1) << pos[b]
+    return 0x7FFFFFF - key
+
+
 @pytest.mark.parametrize("case", ["same", "down", "up3", "up2", "cross"])
 def test_kernel_map(pcc, case):
     c = shell_coords(pcc, grid=40, radius=15.0) * np.array([1, 4, 4, 4], dtype=np.int32)
@@ -153,10 +165,8 @@ def test_kernel_map(pcc, case):
         sm = want_mask[order]
         for g in range(gm.shape[0]):
             assert int(gm[g]) == int(np.bitwise_or.reduce(sm[g * 32:(g + 1) * 32]))
-        if blk < 0:                                 # sorted by (popcount descending, mask ascending)
-            pc = np.array([bin(int(v)).count("1") for v in sm])
-            key = ((27 - pc).astype(np.int64) << 27) | sm
-            assert (np.diff(key) >= 0).all()
+        if blk < 0:                                 # sorted by the rare-offsets-first key
+            assert (np.diff(order_key(want_mask)[order]) >= 0).all()
 
 
 CONV_SHAPES = [
@@ -409,7 +419,7 @@ def test_canonical_sort_all_sizes(pcc, n):
 @pytest.mark.parametrize("n,K", [(5, 27), (257, 27), (16_385, 8), (98_500, 27), (600_003, 27)])
 def test_mask_order_is_the_stable_sort_of_the_keys(pcc, n, K):
     """pcc_order_rows_by_mask on synthetic masks (few distinct values -> long runs of equal keys, the real
-    distribution): `order` must be THE stable ascending sort of (27 - popcount) << 27 | mask — ranks come from
+    distribution): `order` must be THE stable ascending sort of the rare-offsets-first key — ranks come from
     ballots and per-wave counters, never from atomics, so equal keys keep their row order — with the permuted
     table and the 32-position OR-masks consistent with it"""
     from pcc_amd._lib import ptr, check, stream
@@ -427,13 +437,7 @@ def test_mask_order_is_the_stable_sort_of_the_keys(pcc, n, K):
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     check(L.pcc_order_rows_by_mask(ptr(d_mask), None, n, -1, 1, ptr(d_nbr), K, ptr(order), ptr(nbr_s), ptr(gm), ptr(scratch), nbytes,
                                    stream()))
-    pc = np.array([bin(int(v) & 0x7FFFFFF).count("1") for v in palette])
-    popc = np.zeros(n, np.int64)
-    for v, p_ in zip(palette, pc):
-        popc[mask == v] = p_
-    odd = ~np.isin(mask, palette)
-    popc[odd] = [bin(int(v)).count("1") for v in mask[odd]]
-    key = ((27 - popc) << 27) | mask
+    key = order_key(mask)
     want = np.argsort(key, kind="stable")
     got = order.cpu().numpy()
     assert (got == want).all()
