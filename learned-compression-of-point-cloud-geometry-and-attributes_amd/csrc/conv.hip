@@ -1174,6 +1174,14 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
         // bit-identical across configurations.
         const int64_t wgs128 = ((a.n_out + 63) / 64) * (a.coutp / 128);
         if (a.coutp % 128 == 0 && bm == 0 && wgs128 < 768) return launch_mfma<64, 64, 2, 2>(a, st);
+        // Mid-size launches (one to three rounds of 64 x 128 workgroups on 256 CUs x 3) take 32-row tiles — all four waves on
+        // one 32-row MFMA tile, each a 32-column slice: twice the workgroups at 40 KB of LDS (four per CU), so the launch's
+        // last round is fuller, and a workgroup executes exactly the offsets its own 32 rows need.  Measured on the config-2
+        // frame: the 72 k-row layers 0.34-0.51 -> 0.27-0.47 ms (12 launches), no gain from 233 k rows on, a loss on the
+        // 1.26 M-row layers (more weight-slab traffic per MFMA).  PCC_CONV_BM32_MAX=<workgroups> moves the switch (0 = off).
+        static int64_t bm32_max = -1;
+        if (bm32_max < 0) { const char* e = getenv("PCC_CONV_BM32_MAX"); bm32_max = e ? atoll(e) : 3000; }
+        if (a.coutp % 128 == 0 && (bm == 32 || (bm == 0 && wgs128 >= 768 && wgs128 < bm32_max))) return launch_mfma<32, 128, 1, 4>(a, st);
         if (a.coutp % 128 == 0) return bm == 128 ? launch_mfma<128, 128, 2, 2>(a, st) : launch_mfma<64, 128, 2, 2>(a, st);
         if (a.coutp % 64 == 0) return bm == 64 ? launch_mfma<64, 64, 2, 2>(a, st) : launch_mfma<128, 64, 2, 2>(a, st);
         return launch_mfma<128, 32, 4, 1>(a, st);

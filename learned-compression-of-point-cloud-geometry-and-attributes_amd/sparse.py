@@ -456,6 +456,9 @@ def set_infer_x3(enabled):
 PROFILER = None
 
 
+CONV_BM32_MAX = int(os.environ.get("PCC_CONV_BM32_MAX", "3000"))      # mirrors csrc/conv.hip's tile switch (launch names only)
+
+
 def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
     """The kernel pcc_conv_fwd dispatches to, spelled like rocprofv3 prints it (mirrors csrc/conv.hip)."""
     if cin % 32 != 0:
@@ -463,12 +466,13 @@ def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
         return f"conv_thin_kernel<{cin}, {cpt}>"
     coutp = (cout + 31) // 32 * 32
     if coutp % 128 == 0:
-        bm, bn = (64, 64) if ((n_out + 63) // 64) * (coutp // 128) < 768 else (64, 128)
+        wgs128 = ((n_out + 63) // 64) * (coutp // 128)
+        bm, bn = (64, 64) if wgs128 < 768 else (32, 128) if wgs128 < CONV_BM32_MAX else (64, 128)
     elif coutp % 64 == 0:
         bm, bn = 128, 64
     else:
         bm, bn = 128, 32
-    wm, wn = (4, 1) if bn == 32 else (2, 2)
+    wm, wn = (4, 1) if bn == 32 else (1, 4) if bm == 32 else (2, 2)
     return f"conv_mfma_buf_kernel<{bm}, {bn}, {wm}, {wn}, {cin // 32}, {'true' if has_nbr else 'false'}>"
 
 
