@@ -21,8 +21,8 @@ DEV = "cuda:0"
 
 Q_GRID = [(0.05, 0.1), (0.1, 0.2), (0.2, 0.4), (0.4, 0.8)]              # (q_g, q_a), plot.py:31-32
 # (grid, radius): radii in the ratio of the rd_sweep frames (247 : 255 : 261.5 : 294.5 at 1024^3); three frames on
-# a 48^3 grid and the largest on 64^3 keep the 16 oracle runs to about four minutes on the GPU box's host cores
-FRAMES = {"redandblack~": (48, 18.0), "loot~": (48, 18.6), "longdress~": (48, 19.05), "soldier~": (64, 28.6)}
+# a 40^3 grid and the largest on 56^3 keep the 16 oracle runs to about three minutes on the GPU box's host cores
+FRAMES = {"redandblack~": (40, 15.0), "loot~": (40, 15.5), "longdress~": (40, 15.9), "soldier~": (56, 24.0)}
 
 
 @pytest.fixture(scope="module")
@@ -73,14 +73,14 @@ def test_non_uniform_quality_maps_vs_oracle(pcc, model, oracle_codec):
     region of interest (evaluate_view_dep.py)"""
     from pcc_amd import q_map as qm
     syn = pcc.synthetic
-    pts = syn.sphere_shell(grid=48, radius=19.0, half_width=0.5, noise=0.02)
+    pts = syn.sphere_shell(grid=40, radius=15.5, half_width=0.5, noise=0.02)
     N = pts.shape[0]
     coords = np.concatenate([np.zeros((N, 1), np.float32), pts[:, :3]], axis=1)
     cmap = pcc.CoordMap(torch.from_numpy(coords.astype(np.int32)).to(DEV), 1, nbatch=1)
     cases = {
         "gradient_x": qm.gradient_map(cmap, 1),
-        "view_dependent": qm.view_dependent_map(cmap, 0.4, 0.8, 2, 8.0, 40.0),
-        "roi": qm.roi_map(cmap, 0.4, 0.8, 1, 24),
+        "view_dependent": qm.view_dependent_map(cmap, 0.4, 0.8, 2, 6.0, 34.0),
+        "roi": qm.roi_map(cmap, 0.4, 0.8, 1, 20),
     }
     for tag, Q in cases.items():
         qf = Q.F.cpu().numpy()
