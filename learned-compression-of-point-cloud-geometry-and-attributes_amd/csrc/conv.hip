@@ -827,72 +827,6 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
     }
 }
 
-// Thin inputs with wide outputs (2 -> 128, 4 -> 64, 2 -> 256: the q-map branches' first layers and the input layer): one
-// WAVE per output row, one lane per CPT output channels (cout = 64 * CPT).  The lane keeps its K * CIN * CPT weights in
-// registers for the whole launch; the row's neighbour indices and the neighbours' CIN input values are the same for all 64
-// lanes, so they are wave-uniform loads feeding the FMAs as scalar operands, and an absent neighbour is a wave-uniform skip.
-// conv_thin_kernel above reads every weight from LDS for every row (8 FMAs per 32 bytes of LDS, two-way bank conflicts): it is
-// LDS-bound at ~0.27 ms for 2 -> 128 on 265 k rows; this form is bound by its FMAs.  Same fmaf chain (k ascending, channel
-// ascending, absent neighbours skipped), same epilogue: results are bit-identical to conv_thin_kernel's.
-template <int CIN, int CPT>
-__global__ __launch_bounds__(256) void conv_thin_rowwave_kernel(const ConvArgs a) {
-    constexpr int K = 27;
-    const int lane = threadIdx.x & 63;
-    const int cout = a.cout;                       // == 64 * CPT
-    const int co = lane * CPT;
-    float w[K][CIN][CPT];
-#pragma unroll
-    for (int k = 0; k < K; ++k)
-#pragma unroll
-        for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-            for (int j = 0; j < CPT; ++j) w[k][ci][j] = a.w[(k * CIN + ci) * cout + co + j];
-    float bias[CPT];
-#pragma unroll
-    for (int j = 0; j < CPT; ++j) bias[j] = a.bias ? a.bias[co + j] : 0.0f;
-    const int64_t wave0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * 256) >> 6;
-    for (int64_t row = wave0; row < a.n_out; row += nwaves) {
-        const int64_t rowu = ((int64_t)__builtin_amdgcn_readfirstlane((int)(row >> 32)) << 32) |
-                             (uint32_t)__builtin_amdgcn_readfirstlane((int)row);                    // provably wave-uniform
-        const int32_t* nb = a.nbr + rowu * K;
-        float acc[CPT];
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) acc[j] = 0.0f;
-#pragma unroll
-        for (int k0 = 0; k0 < K; k0 += 9) {
-            int idx[9];
-#pragma unroll
-            for (int u = 0; u < 9; ++u) idx[u] = nb[k0 + u];
-            float in[9][CIN];
-#pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                const int64_t src = idx[u] >= 0 ? idx[u] : 0;          // row 0 always exists; its values are not used
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) in[u][ci] = a.fin[src * CIN + ci];
-            }
-#pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                if (idx[u] < 0) continue;                               // wave-uniform
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci)
-#pragma unroll
-                    for (int j = 0; j < CPT; ++j) acc[j] = fmaf(in[u][ci], w[k0 + u][ci][j], acc[j]);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CPT; ++j) {
-            float v = acc[j] + bias[j];
-            if (a.film) {
-                const float* fr = a.film + rowu * (2 * (int64_t)cout);
-                v = v * fr[co + j] + fr[cout + co + j];
-            }
-            v = apply_act(v, a.act);
-            if (a.residual) v += a.residual[rowu * cout + co + j];
-            a.fout[rowu * cout + co + j] = v;
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // narrow heads (cout <= 4 with wide inputs: the occupancy logit, q-map outputs).  Padding cout to a
 // 32-wide MFMA tile would gather every neighbour row (cin * 4 bytes) to produce a handful of
@@ -1063,28 +997,6 @@ static int launch_mfma_x3(const ConvArgs& a, hipStream_t st) {
 
 template <int CIN>
 static int launch_thin(const ConvArgs& a, hipStream_t st) {
-    // wide outputs of a 27-offset kernel: one wave per row, weights in registers (K * CIN * CPT <= 216 per lane)
-    static int rowwave = -1;     // PCC_THIN_ROWWAVE=0: the LDS-weight kernel everywhere (A/B)
-    if (rowwave < 0) { const char* e = getenv("PCC_THIN_ROWWAVE"); rowwave = (e && e[0] == '0') ? 0 : 1; }
-    if (rowwave && a.K == 27 && a.nbr && a.cout % 64 == 0 && CIN * (a.cout / 64) <= 8 && (a.cout / 64) <= 4) {
-        const unsigned nb = blocks_for(a.n_out, 4, 256u * 8u);         // four rows (waves) per block and pass, eight blocks per CU
-        const int cpt = a.cout / 64;
-        bool done = false;
-        // only the (CIN, CPT) pairs whose weights fit the registers are instantiated
-#define PCC_ROWWAVE(CPT)                                                                                              \
-    if constexpr (CIN * CPT <= 8) {                                                                                   \
-        if (cpt == CPT) {                                                                                             \
-            hipLaunchKernelGGL((conv_thin_rowwave_kernel<CIN, CPT>), dim3(nb), dim3(256), 0, st, a);                  \
-            done = true;                                                                                              \
-        }                                                                                                             \
-    }
-        PCC_ROWWAVE(1) PCC_ROWWAVE(2) PCC_ROWWAVE(3) PCC_ROWWAVE(4)
-#undef PCC_ROWWAVE
-        if (done) {
-            PCC_LAUNCH_CHECK();
-            return PCC_OK;
-        }
-    }
     const size_t lds = (size_t)a.K * CIN * a.cout * sizeof(float);
     PCC_REQUIRE(lds <= 64 * 1024, "conv(thin): weights %zu B exceed LDS budget (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
     // channels per thread: the largest of 8, 4, 2, 1 dividing cout

@@ -4,8 +4,6 @@ Bit-exact for integer / index / byte work; fp32 convolution within the tolerance
 each test (the HIP kernels and MKL sgemm sum in different orders).  Run on the MI355X box with
 ``pytest -m gpu``.
 """
-import os
-
 import numpy as np
 import pytest
 import torch
@@ -548,39 +546,3 @@ def test_gaussian_conditional_packed_planes(pcc, oracle_codec):
         back = gc.decompress_features(a, p_sorted, c)
         want = torch.round(feats.index_select(0, perm.long()) - p_sorted[:, c:]) + p_sorted[:, c:]
         assert torch.equal(back, want)
-
-
-def test_thin_rowwave_kernel_is_bit_identical_to_the_lds_weight_kernel(pcc):
-    """conv_thin_rowwave_kernel (one wave per row, weights in registers, wave-uniform neighbour loads) must reproduce
-    conv_thin_kernel bit for bit — same fmaf chain, same epilogue.  The switch is read once per process, so both
-    variants run in child processes and the output digests are compared."""
-    import subprocess
-    import sys
-    code = r"""
-import hashlib, sys, numpy as np, torch
-sys.path.insert(0, %r)
-import pcc_amd
-from pcc_amd import sparse as sp
-torch.manual_seed(3)
-g = np.stack(np.meshgrid(*[np.arange(40)] * 3, indexing="ij"), -1).reshape(-1, 3)
-keep = np.abs(np.linalg.norm(g - 19.5, axis=1) - 15.0) < 0.9
-c = np.concatenate([np.zeros((int(keep.sum()), 1), np.int32), g[keep].astype(np.int32)], axis=1)
-m = pcc_amd.CoordMap(torch.from_numpy(c).to("cuda:0"), 1, nbatch=1)
-h = hashlib.sha256()
-for cin, cout in ((2, 128), (4, 64), (2, 64), (1, 256), (4, 128), (2, 256)):
-    layer = pcc_amd.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).to("cuda:0")
-    with torch.no_grad():
-        layer.kernel.copy_(torch.randn(layer.kernel.shape)); layer.bias.copy_(torch.randn(layer.bias.shape))
-        x = pcc_amd.SparseTensor(torch.randn(m.n, cin, device="cuda:0"), coordinate_map=m)
-        film = torch.randn(m.n, 2 * cout, device="cuda:0"); res = torch.randn(m.n, cout, device="cuda:0")
-        for kw in ({}, dict(act=sp.ACT_RELU, film=film, residual=res), dict(act=sp.ACT_LRELU)):
-            h.update(layer(x, **kw).F.cpu().numpy().tobytes())
-print(h.hexdigest())
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = {}
-    for mode in ("1", "0"):
-        env = dict(os.environ, PCC_THIN_ROWWAVE=mode)
-        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-        out[mode] = r.stdout.strip().splitlines()[-1]
-    assert len(out["1"]) == 64 and out["1"] == out["0"]
