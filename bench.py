@@ -85,6 +85,7 @@ def parse():
                          "fp32 accumulation) on the wide convolutions for the WHOLE run; NOT the headline configuration — a default "
                          "run reports this mode as the `split_bf16` sub-record beside the fp32 value")
     ap.add_argument("--no-x3-record", action="store_true", help="skip the `split_bf16` sub-record of a default run")
+    ap.add_argument("--no-streamed-record", action="store_true", help="skip the `streamed` sub-record of a default run")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -368,6 +369,54 @@ def main():
                      "note": "opt-in (PCC_INFER_X3=1 / bench.py --x3); the headline `value` is the fp32-multiply run above; encoder "
                              "and decoder must run in the same mode"}
 
+    # ---- third record, never `value`: a streamed sequence — two frames in flight on one GPU (two host threads, each on its
+    # own HIP stream), so one frame's serial host range coder runs while the other's kernels do ----
+    streamed_record = None
+    if (not blocks_mode and not args.bf16 and not args.x3 and not args.no_streamed_record and rank == 0 and world == 1
+            and not args.file_mode):
+        import threading
+
+        def run_stream(workers, n_frames):
+            nxt, lock, done, errs = [0], threading.Lock(), [], []
+
+            def worker():
+                try:
+                    s_ = torch.cuda.Stream(device=dev)
+                    with torch.cuda.stream(s_):
+                        while True:
+                            with lock:
+                                i = nxt[0]
+                                nxt[0] += 1
+                            if i >= n_frames:
+                                break
+                            Qs = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)
+                            ss, sshape, sk, sc = model.compress(x, Qs)
+                            srec = model.decompress(coordinates=sc, strings=ss, shape=sshape, k=sk)
+                            done.append((srec.shape[0], pcc_amd.utils.count_bits(ss)))
+                        s_.synchronize()
+                except BaseException as e:               # surfaced below: a worker's failure must fail the bench
+                    errs.append(e)
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            ths = [threading.Thread(target=worker) for _ in range(workers)]
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            torch.cuda.synchronize()
+            if errs:
+                raise errs[0]
+            return time.perf_counter() - ts0, done
+
+        s_frames = max(4, min(12, 2 * args.steps))
+        run_stream(2, 4)                                  # per-thread warm-up (pinned staging, side streams, count words)
+        s_elapsed, s_done = run_stream(2, s_frames)
+        f32_bits = pcc_amd.utils.count_bits(last["strings"])
+        streamed_record = {"value": N * s_frames / s_elapsed / 1e6, "unit": "Mpoints/s", "frames": s_frames, "frames_in_flight": 2,
+                           "ms_per_frame": s_elapsed / s_frames * 1e3,
+                           "streams_equal_to_sequential": bool(all(d == (last["rec"].shape[0], f32_bits) for d in s_done)),
+                           "note": "whole frames, each encoded to bytes and decoded from them; a frame's latency is the sequential "
+                                   "ms_per_step or more — only the throughput of a sequence gains (BASELINE config 4's shape on "
+                                   "one GPU); the headline `value` is the one-frame-at-a-time run above"}
+
     # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
     classes = {}
     pop_cache = {}
@@ -513,6 +562,8 @@ def main():
         out["blocks"] = blocks_record
     if x3_record is not None:
         out["split_bf16"] = x3_record
+    if streamed_record is not None:
+        out["streamed"] = streamed_record
     if file_mode is not None:
         out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

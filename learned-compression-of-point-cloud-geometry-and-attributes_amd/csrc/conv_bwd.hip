@@ -667,6 +667,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 #endif
 }
 
+// A pipelined form of this kernel (two or three image sets, the gathers of the next one / two row groups issued before the
+// MFMAs of the current one, one barrier per group — the slice kernel's loop shape) was built and measured in round 2: SLOWER,
+// 850 k-row shell 128 x 128: 264 TFLOP/s single-buffered, 240 with two image sets, 191 with three (64 x 64: 126 / 116 / 91).
+// At 4.1 TB/s of 256-byte gathers the kernel sits at the gather rate of the memory system; what keeps that rate up is the
+// number of workgroups per CU (16 KB of LDS each), which every extra image set cuts.
 // thin shapes (cin or cout not a multiple of 32: q-map branches, input layer, narrow heads): cin * cout <= 4096.
 // One workgroup per (offset, split).  With >= 256 (ci, co) pairs a thread owns up to 16 pairs and walks the
 // split's rows; with fewer pairs (64 -> 1: the occupancy head on 5 M candidates) the spare threads take

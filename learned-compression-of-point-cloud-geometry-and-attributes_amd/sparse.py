@@ -260,8 +260,8 @@ class SparseTensor:
 # functional operators
 # ---------------------------------------------------------------------------------------------
 def _tracked(*tensors):
-    """True when autograd must see the operation (training path): plain torch indexing ops then stand in for
-    the HIP row movers — same values, differentiable"""
+    """True when autograd must see the operation (training path): the row movers then run as autograd functions
+    over the same HIP kernels (_GatherRowsFn, _ScatterRowsFn, _CompactFeatsFn)"""
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
@@ -302,10 +302,51 @@ def gather_rows(src, idx, out=None, accumulate=False):
     return out
 
 
+class _ScatterRowsFn(torch.autograd.Function):
+    """out[idx[r]] += src[r] (rows with idx < 0 dropped) and its backward d_src[r] = g[idx[r]], both on the HIP row movers"""
+
+    @staticmethod
+    def forward(ctx, src, idx, n_out):
+        src = src.contiguous()
+        out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
+        check(_lib.lib().pcc_scatter_add_rows(ptr(src), src.shape[1], ptr(idx), idx.shape[0], ptr(out), _lib.stream()))
+        ctx.save_for_backward(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = g.contiguous()
+        d = torch.empty((idx.shape[0], g.shape[1]), dtype=torch.float32, device=g.device)
+        check(_lib.lib().pcc_gather_rows(ptr(g), g.shape[1], ptr(idx), idx.shape[0], ptr(d), 0, _lib.stream()))
+        return d, None, None
+
+
+class _CompactFeatsFn(torch.autograd.Function):
+    """Differentiable half of compact_rows: kept rows of ``feats`` in order; backward hands a kept row's gradient back to
+    its source row (new_index = position of a kept row, -1 for a dropped one) and zeros to the dropped rows"""
+
+    @staticmethod
+    def forward(ctx, feats, mask, coords):
+        out_c, out_f, new_index, _ = compact_rows(mask, coords, feats.detach().contiguous(), True)
+        ctx.save_for_backward(new_index)
+        if out_c is None:
+            out_c = new_index.new_empty((0, 4))
+        ctx.mark_non_differentiable(out_c, new_index)
+        return out_f, out_c, new_index
+
+    @staticmethod
+    def backward(ctx, g, _gc, _gi):
+        (new_index,) = ctx.saved_tensors
+        g = g.contiguous()
+        d = torch.empty((new_index.shape[0], g.shape[1]), dtype=torch.float32, device=g.device)
+        check(_lib.lib().pcc_gather_rows(ptr(g), g.shape[1], ptr(new_index), new_index.shape[0], ptr(d), 0, _lib.stream()))
+        return d, None, None
+
+
 def scatter_rows(src, idx, n_out):
     if _tracked(src):
-        ok = idx >= 0
-        return torch.zeros((n_out, src.shape[1]), dtype=src.dtype, device=src.device).index_add(0, idx[ok].long(), src[ok])
+        return _ScatterRowsFn.apply(src, idx.contiguous(), n_out)
     out = torch.zeros((n_out, src.shape[1]), dtype=torch.float32, device=src.device)
     check(_lib.lib().pcc_scatter_rows(ptr(src), src.shape[1], ptr(idx), idx.shape[0], ptr(out), _lib.stream()))
     return out
@@ -314,8 +355,8 @@ def scatter_rows(src, idx, n_out):
 def compact_rows(mask, coords=None, feats=None, want_index=False):
     """Order-preserving compaction (ME.MinkowskiPruning).  Returns (coords, feats, new_index, n)."""
     if _tracked(feats):
-        coords_k, _, new_index, m = compact_rows(mask, coords, None, want_index)
-        return coords_k, feats[mask.bool()], new_index, m
+        feats_k, coords_k, new_index = _CompactFeatsFn.apply(feats, mask, coords)
+        return (coords_k if coords is not None else None), feats_k, (new_index if want_index else None), feats_k.shape[0]
     L = _lib.lib()
     n = mask.shape[0]
     dev = mask.device

@@ -10,6 +10,15 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle runs on torch's intra-op pool, which sizes itself by the HOST's core count; a GPU box hands this
+    # process a 16-core share of a much larger host, and a pool of hundreds of threads on 16 cores makes the oracle's
+    # many small operators several times slower.  Same rule as bench.py's cpu_baseline leg.
+    import torch
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(avail, 16)))
 
 
 def pytest_collection_modifyitems(config, items):

@@ -187,3 +187,39 @@ def test_fused_epilogue_equals_the_torch_chain_bitwise(pcc, act, with_film, with
     assert torch.equal(got, want)
     for a, b in zip(got_g, want_g):
         assert torch.equal(a, b)
+
+
+def test_pruning_and_row_scatter_are_differentiated_in_hip(pcc):
+    """Training-path row movers (ME.MinkowskiPruning, the q-map scatter of model/transforms.py): forward values and
+    gradients of the HIP autograd functions equal torch's boolean indexing / index_add bit for bit"""
+    from pcc_amd import sparse as sp
+    torch.manual_seed(11)
+    n, ch = 5000, 24
+    feats = torch.randn(n, ch, device=DEV, requires_grad=True)
+    mask = (torch.rand(n, device=DEV) < 0.4)
+    coords = torch.randint(0, 100, (n, 4), dtype=torch.int32, device=DEV)
+    want = feats[mask]
+    g = torch.randn_like(want)
+    (want_g,) = torch.autograd.grad(want, feats, g)
+    coords_k, got, new_index, m = sp.compact_rows(mask.to(torch.uint8), coords, feats, want_index=True)
+    assert got.grad_fn is not None and m == int(mask.sum()) and torch.equal(coords_k, coords[mask])
+    assert torch.equal(new_index[mask].long(), torch.arange(m, device=DEV)) and bool((new_index[~mask] == -1).all())
+    (got_g,) = torch.autograd.grad(got, feats, g)
+    assert torch.equal(got, want) and torch.equal(got_g, want_g)
+    # nothing kept / everything kept
+    for mk in (torch.zeros(n, dtype=torch.uint8, device=DEV), torch.ones(n, dtype=torch.uint8, device=DEV)):
+        _, f2, _, m2 = sp.compact_rows(mk, coords, feats)
+        assert m2 == int(mk.sum()) and torch.equal(f2, feats[mk.bool()])
+        (g2,) = torch.autograd.grad(f2.sum(), feats)
+        assert torch.equal(g2, mk.float().reshape(-1, 1).expand(n, ch))
+    # scatter: unique targets, some rows dropped
+    n_out = 7000
+    idx = torch.randperm(n_out, device=DEV)[:n].to(torch.int32)
+    idx[::7] = -1
+    ok = idx >= 0
+    want = torch.zeros((n_out, ch), device=DEV).index_add(0, idx[ok].long(), feats[ok])
+    g = torch.randn_like(want)
+    (want_g,) = torch.autograd.grad(want, feats, g)
+    got = sp.scatter_rows(feats, idx, n_out)
+    (got_g,) = torch.autograd.grad(got, feats, g)
+    assert torch.equal(got, want) and torch.equal(got_g, want_g)
