@@ -163,6 +163,15 @@ int pcc_epilogue_fwd(const float* c, const float* film, const float* residual, i
 int pcc_epilogue_bwd(const float* dout, const float* c, const float* film, int64_t n, int32_t channels, int32_t act,
                      float* dc, float* dfilm, void* stream);
 
+/* dY of a convolution read once on the training path (autograd.py, SparseConvFn.backward): out_bf16 (may be NULL) = the
+ * bf16 copy the bf16 weight-gradient / backward-data kernels gather (round to nearest even, torch's conversion), colsum
+ * (may be NULL) = the column sums = the bias gradient (ME differentiates `out + bias`, reference blocks.py convolutions
+ * with bias=True).  Deterministic two-stage reduction; scratch: pcc_cast_colsum_scratch_elems(channels) floats.
+ * channels % 4 == 0, <= 1024; x 16-byte aligned. */
+int64_t pcc_cast_colsum_scratch_elems(int32_t channels);
+int pcc_cast_colsum(const float* x, int64_t n, int32_t channels, uint16_t* out_bf16, float* colsum, float* scratch,
+                    int64_t scratch_elems, void* stream);
+
 /* Split-bf16 arithmetic on fp32 data (opt-in; the default convolution multiplies in fp32): every fp32 operand is
  * the exact sum of three bf16 numbers; the weights are pre-split into three planes (pcc_conv_pack_weights_x3,
  * pcc_conv_packed_elems_x3 bf16 elements), the gathered fp32 rows are split in registers, and the six products

@@ -155,16 +155,28 @@ class SparseConvFn(torch.autograd.Function):
         n_in, n_out = feats.shape[0], dy.shape[0]
         dev = dy.device
         d_feats = d_kernel = d_bias = None
+        bf = feats.dtype == torch.bfloat16                 # forward ran in bf16: the saved input is the bf16 copy
+        want_db = has_bias and ctx.needs_input_grad[2]
+        # dY is read once for its bf16 copy (weight gradient, backward-data) and its column sums (bias gradient)
+        dy_bf = db = None
+        if (want_db or (bf and ctx.needs_input_grad[1])) and cout % 4 == 0 and cout <= 1024:
+            if bf and ctx.needs_input_grad[1]:
+                dy_bf = torch.empty((n_out, cout), dtype=torch.bfloat16, device=dev)
+            if want_db:
+                db = torch.empty(cout, dtype=torch.float32, device=dev)
+            ne_cs = L.pcc_cast_colsum_scratch_elems(cout)
+            cs_scratch = torch.empty(ne_cs if want_db else 0, dtype=torch.float32, device=dev)
+            check(L.pcc_cast_colsum(ptr(dy), n_out, cout, ptr(dy_bf), ptr(db), ptr(cs_scratch) if want_db else None, ne_cs,
+                                    _lib.stream()))
 
         if ctx.needs_input_grad[1]:
             # Thin shapes (q-map branches, input layer, narrow heads) are zero-padded to 32 channels and take the MFMA
             # kernel too: the scalar kernel walks its rows serially and needs 60 ms for 2 -> 128 on 3.4 M rows where
             # the padded MFMA launch takes 7 (16x the multiplications, all of them in the matrix pipe).
-            bf = feats.dtype == torch.bfloat16             # forward ran in bf16: the saved input is the bf16 copy
             unit = 64 if bf else 32
             cin_p, cout_p = (cin + unit - 1) // unit * unit, (cout + unit - 1) // unit * unit
             x_w = feats
-            g_w = dy.to(torch.bfloat16) if bf else dy
+            g_w = (dy_bf if dy_bf is not None else dy.to(torch.bfloat16)) if bf else dy
             if cin_p != cin:
                 x_w = torch.cat([x_w, torch.zeros((n_in, cin_p - cin), dtype=x_w.dtype, device=dev)], dim=1)
             if cout_p != cout:
@@ -191,8 +203,9 @@ class SparseConvFn(torch.autograd.Function):
                 dw = full
             d_kernel = dw.reshape(kshape)
 
-        if has_bias and ctx.needs_input_grad[2]:
-            db = dy.sum(dim=0)
+        if want_db:
+            if db is None:
+                db = dy.sum(dim=0)
             if out_channels is not None:
                 full = torch.zeros(kshape[-1], dtype=torch.float32, device=dev)
                 full[:out_channels] = db

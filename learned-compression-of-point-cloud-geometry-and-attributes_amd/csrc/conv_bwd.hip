@@ -672,6 +672,99 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradArgs a)
 // 850 k-row shell 128 x 128: 264 TFLOP/s single-buffered, 240 with two image sets, 191 with three (64 x 64: 126 / 116 / 91).
 // At 4.1 TB/s of 256-byte gathers the kernel sits at the gather rate of the memory system; what keeps that rate up is the
 // number of workgroups per CU (16 KB of LDS each), which every extra image set cuts.
+// 64 -> 64 with bf16 operands and 27 offsets: a row pair is 2 x 128 B for 8 k FLOP and the kernel above runs at the gather rate
+// of the memory system (~4 TB/s of rows), so the only lever is bytes: a workgroup owns O consecutive offsets and a group's
+// 32 dY rows are staged ONCE for all of the O that occur in the group (4 + 4 L KB per L live offsets instead of 8 L), each
+// offset's X rows in its own image.  Single-buffered like the kernel above (occupancy carries the latency): one staging
+// instruction per thread and image — wave w stages rows 8 w .. 8 w + 7 of every image — then wave (tm, tn) runs its 32 x 32
+// tile of every live offset against the shared dY operand: per MFMA k-step one dY fragment, L X fragments, L MFMAs.
+template <int O>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_slice_kernel(const WgradArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* Xs = reinterpret_cast<unsigned short*>(smem);             // [O][32 rows][64 ch]
+    unsigned short* Ys = Xs + O * 2048;                                       // [32 rows][64 co]
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
+    const int SPLIT = a.split;
+    const int set = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
+    const int k0 = set * O;
+    const uint32_t set_mask = (((1u << O) - 1u) << k0) & ((1u << a.K) - 1u);
+    const int tm = wave_u >> 1, tn = wave_u & 1;
+
+    f32x16 acc[O];
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[o][j] = 0.0f;
+
+    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 2), WG_FLAGS);
+    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(uint32_t)(a.n_out * a.cout * 2), WG_FLAGS);
+    const int64_t ng = (a.n_out + 31) >> 5;
+    const int slot = lane & 7, rsub = lane >> 3;
+    const int tr_off = (((lane & 15) >> 2) * 64) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    for (int64_t gbase = s; gbase < ng; gbase += 64 * (int64_t)SPLIT) {
+        const int64_t gmine = gbase + (int64_t)lane * SPLIT;
+        const uint32_t gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
+        unsigned long long todo = __ballot((gml & set_mask) != 0u);
+        while (todo) {
+            const int bit = __ffsll(todo) - 1;
+            todo &= todo - 1;
+            const int64_t g = gbase + (int64_t)bit * SPLIT;
+            const uint32_t rem = (uint32_t)__builtin_amdgcn_readfirstlane((int)(((uint32_t)__shfl((int)gml, bit, 64) & set_mask) >> k0));
+            const int64_t pos = g * 32 + 8 * wave_u + rsub;
+            const bool ok = pos < a.n_out;
+            {
+                const int yrow = ok ? (a.order ? a.order[pos] : (int)pos) : -1;
+                const uint32_t vo = yrow >= 0 ? (uint32_t)yrow * (uint32_t)(a.cout * 2) + (uint32_t)(slot * 16) : WG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Ys + wave_u * 512), 16, vo, 0, 0, 0);
+            }
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                if (!((rem >> o) & 1u)) continue;
+                const int idx = ok ? a.nbr[pos * a.K + k0 + o] : -1;
+                const uint32_t vo = idx >= 0 ? (uint32_t)idx * (uint32_t)(a.cin * 2) + (uint32_t)(slot * 16) : WG_OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(Xs + o * 2048 + wave_u * 512), 16, vo, 0, 0, 0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int row0 = 16 * ks + 8 * h;
+                const unsigned short* bp = Ys + row0 * 64 + tn * 32 + tr_off;
+                const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp));
+                const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bp + 4 * 64));
+                const s16x8 b8 = {blo[0], blo[1], blo[2], blo[3], bhi[0], bhi[1], bhi[2], bhi[3]};
+                const bf16x8 bop = __builtin_bit_cast(bf16x8, b8);
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    if (!((rem >> o) & 1u)) continue;                       // wave-uniform: EXEC stays all ones
+                    const unsigned short* ap = Xs + o * 2048 + row0 * 64 + tm * 32 + tr_off;
+                    const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap));
+                    const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ap + 4 * 64));
+                    const s16x8 a8 = {alo[0], alo[1], alo[2], alo[3], ahi[0], ahi[1], ahi[2], ahi[3]};
+                    acc[o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a8), bop, acc[o], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int o = 0; o < O; ++o) {
+        if (k0 + o >= a.K) break;
+        float* P = a.partial + ((int64_t)s * a.K + (k0 + o)) * a.cin * a.cout;
+        const int co = tn * 32 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int ci = tm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            P[(int64_t)ci * a.cout + co] = acc[o][reg];
+        }
+    }
+#endif
+}
+
 // thin shapes (cin or cout not a multiple of 32: q-map branches, input layer, narrow heads): cin * cout <= 4096.
 // One workgroup per (offset, split).  With >= 256 (ci, co) pairs a thread owns up to 16 pairs and walks the
 // split's rows; with fewer pairs (64 -> 1: the occupancy head on 5 M candidates) the spare threads take
@@ -866,6 +959,27 @@ int pcc_conv_wgrad_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const ui
     a.gmask = group_mask32; a.partial = scratch; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.K = K;
     a.split = wgrad_splits(n_out);
     PCC_REQUIRE(scratch_elems >= (int64_t)a.split * elems, "pcc_conv_wgrad_bf16: scratch too small");
+    // 64 -> 64, 27 offsets: the slice kernel (PCC_WGRAD_BF16_SLICE_O=0 keeps the one-offset kernel; 3 | 5 | 9 offsets per
+    // workgroup).  850 k-row / 265 k-row shells, same box: one-offset 122-124 / 129 TFLOP/s, O = 3 137 / 135 (71 registers, 7 waves
+    // per SIMD), O = 5 121 / 119 (103 registers), O = 9 140 / 125 (167 registers): fewer bytes and fewer waves trade evenly
+    static int slice_o = -1;
+    if (slice_o < 0) {
+        const char* e = getenv("PCC_WGRAD_BF16_SLICE_O");
+        slice_o = e ? atoi(e) : 3;
+        if (slice_o != 0 && slice_o != 3 && slice_o != 5 && slice_o != 9) slice_o = 3;
+    }
+    if (slice_o && cin == 64 && cout == 64 && K == 27) {
+        a.split = wgrad_slice_splits(n_out);
+        PCC_REQUIRE(scratch_elems >= (int64_t)a.split * elems, "pcc_conv_wgrad_bf16: scratch too small");
+        const unsigned sets = (unsigned)((K + slice_o - 1) / slice_o);
+        const size_t lds = (size_t)(slice_o + 1) * 2048 * sizeof(unsigned short);
+        if (slice_o == 3) hipLaunchKernelGGL(conv_wgrad_bf16_slice_kernel<3>, dim3(sets * a.split), dim3(256), lds, st, a);
+        else if (slice_o == 5) hipLaunchKernelGGL(conv_wgrad_bf16_slice_kernel<5>, dim3(sets * a.split), dim3(256), lds, st, a);
+        else hipLaunchKernelGGL(conv_wgrad_bf16_slice_kernel<9>, dim3(sets * a.split), dim3(256), lds, st, a);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, a.split, dw);
+        PCC_LAUNCH_CHECK();
+        return PCC_OK;
+    }
     const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
     hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), 4 * 2048 * sizeof(unsigned short), st, a);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, a.split, dw);

@@ -223,3 +223,40 @@ def test_pruning_and_row_scatter_are_differentiated_in_hip(pcc):
     got = sp.scatter_rows(feats, idx, n_out)
     (got_g,) = torch.autograd.grad(got, feats, g)
     assert torch.equal(got, want) and torch.equal(got_g, want_g)
+
+
+@pytest.mark.parametrize("n,ch", [(1, 4), (777, 64), (5000, 100), (100003, 128), (3000, 256), (300, 1024), (0, 64)])
+def test_cast_and_column_sums_in_one_pass(pcc, n, ch):
+    """pcc_cast_colsum (the convolution backward's single read of dY): the bf16 copy equals torch's conversion bit for bit
+    (round to nearest even, infinities, NaN), the column sums equal a float64 sum to fp32 rounding and are deterministic"""
+    from pcc_amd import _lib
+    from pcc_amd._lib import check, ptr
+    L = pcc.lib()
+    torch.manual_seed(n + ch)
+    x = (torch.randn(n, ch) * torch.exp(torch.randn(n, ch) * 4)).to(DEV)
+    if n > 2:
+        x[0, 0], x[1, 1], x[2, 2] = float("inf"), float("-inf"), 0.0
+        x[2, 3] = torch.tensor(0x3F808000, dtype=torch.int32).view(torch.float32)      # exactly halfway: ties to even
+    ne = L.pcc_cast_colsum_scratch_elems(ch)
+    scratch = torch.empty(ne, dtype=torch.float32, device=DEV)
+    out = torch.empty((n, ch), dtype=torch.bfloat16, device=DEV)
+    cs = torch.full((ch,), 7.0, device=DEV)
+    check(L.pcc_cast_colsum(ptr(x), n, ch, ptr(out), ptr(cs), ptr(scratch), ne, _lib.stream()))
+    assert torch.equal(out.view(torch.int16), x.to(torch.bfloat16).view(torch.int16))
+    finite = torch.nan_to_num(x, posinf=0.0, neginf=0.0) if n > 2 else x
+    if n > 2:                                                   # the infinities make their columns inf / -inf
+        assert cs[0] == float("inf") and cs[1] == -float("inf")
+    want = finite.double().sum(0)
+    scale = finite.double().abs().sum(0) + 1e-30
+    ok = torch.ones(ch, dtype=torch.bool, device=DEV)
+    if n > 2:
+        ok[:2] = False
+    assert bool((((cs.double() - want).abs() / scale)[ok] < 1e-6).all())
+    cs2 = torch.empty_like(cs)
+    check(L.pcc_cast_colsum(ptr(x), n, ch, None, ptr(cs2), ptr(scratch), ne, _lib.stream()))
+    assert torch.equal(cs2[ok], cs[ok])
+    if n > 0:
+        xn = x.clone()
+        xn[0, 0] = float("nan")
+        check(L.pcc_cast_colsum(ptr(xn), n, ch, ptr(out), None, None, 0, _lib.stream()))
+        assert torch.equal(out.view(torch.int16), xn.to(torch.bfloat16).view(torch.int16))
