@@ -301,7 +301,7 @@ def main():
             payload = b"".join(par.pack_items_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
             if world > 1:
                 par.all_gather_bitstreams(payload, cdev)
-            return units, parts_, (0 if rec_ is None else rec_.shape[0])
+            return units, parts_, (0 if rec_ is None else rec_.shape[0]), rec_
 
         blocks_step()                                               # warm-up: kernel maps of the cube sizes, caches
         if dist is not None:
@@ -309,7 +309,7 @@ def main():
         torch.cuda.synchronize()
         tb0 = time.perf_counter()
         for _ in range(b_steps):
-            b_units, b_parts, b_dec = blocks_step()
+            b_units, b_parts, b_dec, b_rec = blocks_step()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -329,6 +329,18 @@ def main():
                          "note": "one frame per step, its cubes coded as batch items of one compress call per rank "
                                  "(per-item k and top-k), containers all-gathered; a different partition gives "
                                  "different numbers than whole-frame coding (parity target: the oracle on the same items)"}
+
+        if world == 1 and b_rec is not None:
+            # the block partition changes the numbers — report them beside the whole-frame ones
+            from pcc_amd.metrics import PointCloudMetric
+            res_b = cfg["grid"] - 1
+            mb, _ = PointCloudMetric(xb, b_rec, resolution=res_b).compute_pointcloud_metrics(drop_duplicates=True)
+            mw, _ = PointCloudMetric(x, last["rec"], resolution=res_b).compute_pointcloud_metrics(drop_duplicates=True)
+            w_bpp = pcc_amd.utils.count_bits(last["strings"]) / N
+            blocks_record["d1_psnr_db"], blocks_record["y_psnr_db"] = float(mb["sym_psnr_mse"]), float(mb["sym_y_psnr"])
+            blocks_record["delta_vs_whole_frame"] = {"bpp": blocks_record["bpp"] - w_bpp,
+                                                     "d1_psnr_db": float(mb["sym_psnr_mse"]) - float(mw["sym_psnr_mse"]),
+                                                     "y_psnr_db": float(mb["sym_y_psnr"]) - float(mw["sym_y_psnr"])}
 
     # ---- second record, never `value`: the same frame with split-bf16 arithmetic on the wide convolutions ----
     x3_record = None

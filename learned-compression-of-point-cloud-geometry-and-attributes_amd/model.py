@@ -102,6 +102,12 @@ class ColorModel(nn.Module):
         c8 = CoordMap(sp._as_int_coords(coordinates.to(device)), 8, nbatch=nbatch)
         c32 = c8.down().down()      # coordinates only (g_s.down_conv applied twice, model.py:188-190)
         y_hat, Q_hat = self.entropy_model.decompress([c8, c32], strings, shape)
+        return self.reconstruct(y_hat, Q_hat, k, return_batch)
+
+    @torch.no_grad()
+    def reconstruct(self, y_hat, Q_hat, k, return_batch=False):
+        """The second half of decompress (model/model.py:196-208): g_s on entropy-decoded latents, 8-bit colour rounding.
+        Public so that a decoder can be checked on latents it did not decode itself (tests/_parity.py)."""
         x_hat = self.g_s(y_hat, Q_hat, k=k)
         feats = torch.clamp(torch.round(x_hat.F * 255), 0.0, 255.0) / 255
         points = torch.cat([x_hat.C[:, 1:4].to(feats.dtype), feats], dim=1)
