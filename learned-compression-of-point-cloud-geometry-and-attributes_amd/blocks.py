@@ -66,6 +66,11 @@ class ScaledBlock(nn.Module):
             film = condition.F
         else:
             film = condition.features_at_coordinates(x.C)
+        N = x.F.shape[1]
+        if film.shape[1] == 2 and N != 1:
+            # condition_ablation (blocks.py:246-247 hands the 2-channel q-map itself to blocks.py:37-40): beta and gamma are
+            # one column each and broadcast over the channels
+            film = torch.cat([film[:, :1].expand(-1, N), film[:, 1:].expand(-1, N)], dim=1).contiguous()
         h = self.conv_1(x, last_film=film if self.scale else None)
         return self.conv_2(h, last_residual=x.F)
 
@@ -129,11 +134,12 @@ class GenerativeUpBlock(nn.Module):
     def forward(self, x, coords=None, k=None, full_predictions=False):
         if not self.predict:
             return self._follow(x, coords)
-        if not self.dense or self.condition_ablation is not None:
-            raise NotImplementedError("dense=False / condition_ablation variants are outside BASELINE scope")
         _join_prefetch(x.map)
         x = self.conv(x)                                   # genConvT k3 s2 -> all candidates
-        x = self.conv_2(x)
+        # blocks.py:156-175: dense (the shipped configs) refines the candidates before the occupancy head; dense=False
+        # predicts on the raw candidates and refines the kept rows; condition_ablation drops conv_2 in either order
+        if self.dense and self.condition_ablation is None:
+            x = self.conv_2(x)
         # only channel 0 of the occupancy head is ever read (blocks.py:142): evaluate just that
         # column unless the caller wants the full tensor (training losses).
         pred = self.occ_predict(x, last_out_channels=None if full_predictions else 1)
@@ -141,7 +147,10 @@ class GenerativeUpBlock(nn.Module):
         mask = sp.topk_mask(pred.F, pred.C, k, nb)
         coords_kept, feats_kept, _, _ = sp.compact_rows(mask, x.C, x.F)
         up_map = CoordMap(coords_kept, x.map.stride, nbatch=x.map._nbatch)
-        return SparseTensor(feats_kept, coordinate_map=up_map), pred, up_map
+        x = SparseTensor(feats_kept, coordinate_map=up_map)
+        if not self.dense and self.condition_ablation is None:
+            x = self.conv_2(x)
+        return x, pred, up_map
 
     def _follow(self, Q, up_map):
         """predict=False (q_up_i, blocks.py:179-181): genConvT then prune to the kept coordinates.
@@ -183,11 +192,13 @@ class ConditionEncoder(nn.Module):
             self.register_parameter(f"{name}_{pid}".replace(".", "_"), param)
 
     def forward(self, Q):
-        if self.condition_ablation is not None:
-            raise NotImplementedError("condition_ablation is outside BASELINE scope (configs/Ours.yaml)")
+        if self.condition_ablation not in (None, "condition_ablation"):
+            raise ValueError(f"condition_ablation={self.condition_ablation!r}: the reference defines None and "
+                             "'condition_ablation' only (blocks.py:244-247)")
         Q = self.pre_conv(Q)
         beta_gammas = []
         for i in range(self.num_stages):
             Q = self.down_layers[i](Q)
-            beta_gammas.append(self.predict_layers[i](Q))
+            # configs/Ablation_NoCondition_Convolution.yaml: the down-sampled q-map itself is the (1 + 1)-channel beta | gamma
+            beta_gammas.append(self.predict_layers[i](Q) if self.condition_ablation is None else Q)
         return Q, beta_gammas

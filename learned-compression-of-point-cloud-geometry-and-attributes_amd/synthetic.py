@@ -21,6 +21,14 @@ OURS_CONFIG = {
     "g_s": {"C_out": 3, "N1": 128, "N2": 128, "N3": 64, "source_condition": True},
 }
 
+# the ``model:`` section of /root/reference/configs/Ablation_NoCondition_Convolution.yaml:6-25 (Ablation_200_logarithmic.yaml's
+# model section equals Ours.yaml's): no source-conditioned q-map correction, the down-sampled q-map itself as beta | gamma
+ABLATION_NOCONDITION_CONFIG = {
+    "entropy_model": {"type": "MeanScaleHyperprior_map", "C_bottleneck": 128, "C_hyper_bottleneck": 128, "C_Q": 2},
+    "g_a": {"C_in": 4, "N1": 64, "N2": 128, "N3": 128, "source_condition": False, "condition_ablation": "condition_ablation"},
+    "g_s": {"C_out": 3, "N1": 128, "N2": 128, "N3": 64, "source_condition": False, "condition_ablation": "condition_ablation"},
+}
+
 CONFIG1 = dict(grid=32, radius=15.0, half_width=0.875)       # N = 4,904
 CONFIG2 = dict(grid=1024, radius=260.0, half_width=0.5)      # N = 850,824
 

@@ -119,8 +119,7 @@ class SparseSynthesisTransform(nn.Module):
         self.down_conv = MinkowskiConvolution(in_channels=1, out_channels=1, kernel_size=3, stride=2, dimension=3)
 
     def forward(self, x, Q, coords=None, k=None):
-        if self.condition_ablation is not None:
-            raise NotImplementedError("condition_ablation is outside BASELINE scope (configs/Ours.yaml)")
+        # condition_ablation reaches only the q_up_i blocks here, whose predict=False branch never reads it (blocks.py:179-181)
         full_pred = coords is not None
         aligned = _align(Q, x.map)
         if aligned is not None:

@@ -26,7 +26,7 @@ def scaled_block(p, x, condition):
     h = p.sub("conv_1").conv(x, "0")
     h = on.relu(h)
     h = p.sub("conv_1").conv(h, "2")
-    beta, gamma = condition.features_at_coordinates(h.C).chunk(2, dim=1)
+    beta, gamma = condition.features_at_coordinates(h.C).chunk(2, dim=1)       # [n, N] each, or [n, 1] (condition_ablation): broadcast
     h2 = SparseTensor(h.C, h.F * beta + gamma, h.stride)
     h2._cache = h._cache
     h = p.sub("conv_2").conv(h2, "0")
@@ -63,18 +63,22 @@ def prune_by_coords(x, keep_coords):
     return on.prune(x, mask)
 
 
-def up_block_predict(p, x, k):
-    """blocks.py:152-177, predict=True, dense=True."""
+def up_block_predict(p, x, k, dense=True, condition_ablation=None):
+    """blocks.py:152-177, predict=True; dense=False (:168-175) predicts on the raw candidates and refines the kept rows."""
+    def conv_2(t):
+        h = on.relu(p.sub("conv_2").conv(t, "0"))
+        return p.sub("conv_2").conv(h, "2")
     x = p.convT(x, "conv", 3)
-    h = p.sub("conv_2").conv(x, "0")
-    h = on.relu(h)
-    x = p.sub("conv_2").conv(h, "2")
+    if dense and condition_ablation is None:
+        x = conv_2(x)
     h = p.sub("occ_predict").conv(x, "0")
     h = on.relu(h)
     pred = p.sub("occ_predict").conv(h, "2")
     mask = topk_mask(pred, k)
     up_coords = pred.C[mask]
     x = prune_by_coords(x, up_coords)
+    if not dense and condition_ablation is None:
+        x = conv_2(x)
     return x, pred, up_coords
 
 
@@ -84,12 +88,15 @@ def up_block_follow(p, Q, up_coords):
     return prune_by_coords(Q, up_coords)
 
 
-def condition_encoder(p, Q):
-    """blocks.py:235-251 (conv_layers skipped: blocks.py:241)."""
+def condition_encoder(p, Q, condition_ablation=None):
+    """blocks.py:235-251 (conv_layers skipped: blocks.py:241; condition_ablation: the q-map itself is beta | gamma, :246-247)."""
     Q = on.relu(p.sub("pre_conv").conv(Q, "0"))
     bgs = []
     for i in range(3):
         Q = p.sub("down_layers").conv(Q, str(i), 3, 2)
+        if condition_ablation is not None:
+            bgs.append(Q)
+            continue
         pl = p.sub("predict_layers").sub(str(i))
         h = on.relu(pl.conv(Q, "0"))
         h = on.relu(pl.conv(h, "2", ksize=1))
@@ -100,13 +107,16 @@ def condition_encoder(p, Q):
 # ----------------------------------------------------------------------------------------
 # transforms.py
 # ----------------------------------------------------------------------------------------
-def analysis(p, x, Q):
-    """transforms.py:75-128."""
+def analysis(p, x, Q, cfg=None):
+    """transforms.py:75-128.  ``cfg``: the g_a section of the model config (source_condition, condition_ablation);
+    None = configs/Ours.yaml."""
+    cfg = cfg or {}
     k = [oc.count_per_batch(x.C)]
-    h = on.relu(p.sub("cond_conv").conv(x, "0"))
-    Q_plus = p.sub("cond_conv").conv(h, "2")
-    Q = SparseTensor(Q.C, Q.F + Q_plus.features_at_coordinates(Q.C), 1)
-    Q, bgs = condition_encoder(p.sub("condition_encoder"), Q)
+    if cfg.get("source_condition", True):
+        h = on.relu(p.sub("cond_conv").conv(x, "0"))
+        Q_plus = p.sub("cond_conv").conv(h, "2")
+        Q = SparseTensor(Q.C, Q.F + Q_plus.features_at_coordinates(Q.C), 1)
+    Q, bgs = condition_encoder(p.sub("condition_encoder"), Q, cfg.get("condition_ablation"))
     x = on.relu(p.sub("pre_conv").conv(x, "0"))
     x = p.conv(x, "down_1", 3, 2)
     x = scaled_block(p.sub("scale_1"), x, bgs[0])
@@ -122,11 +132,13 @@ def analysis(p, x, Q):
     return x, Q8, k
 
 
-def synthesis(p, x, Q, k, coords=None):
-    """transforms.py:242-304."""
-    h = on.relu(p.sub("cond_conv").conv(x, "0"))
-    Q_plus = p.sub("cond_conv").conv(h, "2")
-    Q = SparseTensor(Q.C, Q.F + Q_plus.features_at_coordinates(Q.C), Q.stride)
+def synthesis(p, x, Q, k, coords=None, cfg=None):
+    """transforms.py:242-304.  ``cfg``: the g_s section of the model config (source_condition, dense); None = Ours.yaml."""
+    cfg = cfg or {}
+    if cfg.get("source_condition", True):
+        h = on.relu(p.sub("cond_conv").conv(x, "0"))
+        Q_plus = p.sub("cond_conv").conv(h, "2")
+        Q = SparseTensor(Q.C, Q.F + Q_plus.features_at_coordinates(Q.C), Q.stride)
     x = on.relu(p.sub("pre_conv").conv(x, "0"))
     qp = p.sub("q_pre_conv")
     Q = qp.conv(on.relu(qp.conv(on.relu(qp.conv(Q, "0")), "2", ksize=1)), "4")
@@ -135,7 +147,7 @@ def synthesis(p, x, Q, k, coords=None):
         qq = p.sub(f"q_predict_{i}")
         bg = qq.conv(on.relu(qq.conv(on.relu(qq.conv(Q, "0")), "2")), "4")
         x = scaled_block(p.sub(f"scale_{i}"), x, bg)
-        x, pred, up_coords = up_block_predict(p.sub(f"up_{i}"), x, k[i - 1])
+        x, pred, up_coords = up_block_predict(p.sub(f"up_{i}"), x, k[i - 1], dense=cfg.get("dense", True))
         Q = up_block_follow(p.sub(f"q_up_{i}"), Q, up_coords)
         preds.append(pred)
     pc = p.sub("post_conv")
@@ -179,7 +191,11 @@ def h_q(p, z):
 class Codec:
     """Functional restatement of ``ColorModel`` (model/model.py:15-208)."""
 
-    def __init__(self, state_dict):
+    def __init__(self, state_dict, config=None):
+        """``config``: the model section of the yaml ({"g_a": {...}, "g_s": {...}, ...}); None = configs/Ours.yaml.  Only the
+        switches that change the forward pass are read: source_condition, condition_ablation (g_a), dense (g_s)."""
+        self.cfg_a = dict((config or {}).get("g_a", {}))
+        self.cfg_s = dict((config or {}).get("g_s", {}))
         self.sd = {k: torch.as_tensor(v).detach().to(torch.float32).cpu() for k, v in state_dict.items()
                    if torch.as_tensor(v).dtype.is_floating_point}
         self.p = Params(self.sd)
@@ -213,7 +229,7 @@ class Codec:
         feats = torch.from_numpy(np.concatenate([np.ones((N, 1), np.float32), x[:, 3:6]], axis=1))
         inp = SparseTensor(pts, feats, 1)
         Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
-        y, _, k = analysis(self.p.sub("g_a"), inp, Q)
+        y, _, k = analysis(self.p.sub("g_a"), inp, Q, self.cfg_a)
         em = self.p.sub("entropy_model")
         z = h_a(em.sub("h_a"), y)
         y = y.sorted()
@@ -252,7 +268,7 @@ class Codec:
         indexes = self.gc.build_indexes(scales)
         y_hat = self.gc.decompress(strings[0], indexes, means)
         y_hat = SparseTensor(y_pts, y_hat[0].t().contiguous(), 8)
-        x_hat = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k)
+        x_hat = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k, cfg=self.cfg_s)
         feats = torch.clamp(torch.round(x_hat.F * 255), 0.0, 255.0) / 255
         self.last_dec = dict(y_hat=y_hat, Q_hat=Q_hat, x_hat=x_hat)
         self.last_batch = x_hat.C[:, 0].copy()
@@ -265,7 +281,7 @@ class Codec:
         feats = torch.cat([torch.ones((N, 1)), torch.as_tensor(colors, dtype=torch.float32)], dim=1)
         x = SparseTensor(coords, feats, 1)
         Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
-        y, _, k = analysis(self.p.sub("g_a"), x, Q)
+        y, _, k = analysis(self.p.sub("g_a"), x, Q, self.cfg_a)
         em = self.p.sub("entropy_model")
         z = h_a(em.sub("h_a"), y)
         z_hat_f, z_lik = self.eb.forward_eval(z.F.t().unsqueeze(0))
@@ -276,7 +292,7 @@ class Codec:
         scales, means = gp.chunk(2, dim=1)
         y_hat_f, y_lik = self.gc.forward_eval(y.F.t().unsqueeze(0), scales.t().unsqueeze(0), means.t().unsqueeze(0))
         y_hat = SparseTensor(y.C, y_hat_f[0].t().contiguous(), 8)
-        x_hat, points, preds = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k, coords=coords)
+        x_hat, points, preds = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k, coords=coords, cfg=self.cfg_s)
         return {"prediction": x_hat, "points": points, "occ_predictions": preds,
                 "likelihoods": {"y": y_lik, "z": z_lik}, "k": k}
 

@@ -46,7 +46,7 @@ def forward_train(codec, coords, colors, Q_coords, Q_feats, noise):
     feats = torch.cat([torch.ones((N, 1)), torch.as_tensor(colors, dtype=torch.float32)], dim=1)
     x = SparseTensor(coords, feats, 1)
     Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
-    y, _, k = analysis(codec.p.sub("g_a"), x, Q)
+    y, _, k = analysis(codec.p.sub("g_a"), x, Q, getattr(codec, "cfg_a", None))
     em = codec.p.sub("entropy_model")
     z = h_a(em.sub("h_a"), y)
     v = z.F.t().unsqueeze(0).permute(1, 0, 2)                        # [C, 1, N]
@@ -65,7 +65,7 @@ def forward_train(codec, coords, colors, Q_coords, Q_feats, noise):
     Phi = codec.gc._Phi
     y_lik = _LowerBound.apply(Phi((0.5 - a) / s) - Phi((-0.5 - a) / s), LIKELIHOOD_BOUND)
     y_hat = SparseTensor(y.C, yout[0].t().contiguous(), 8)
-    x_hat, points, preds = synthesis(codec.p.sub("g_s"), y_hat, Q_hat, k, coords=coords)
+    x_hat, points, preds = synthesis(codec.p.sub("g_s"), y_hat, Q_hat, k, coords=coords, cfg=getattr(codec, "cfg_s", None))
     return {"prediction": x_hat, "points": points, "occ_predictions": preds, "likelihoods": {"y": y_lik, "z": z_lik}, "k": k}
 
 
