@@ -10,9 +10,7 @@ import torch
 
 from oracle import coords as oc
 from oracle import nn as on
-from oracle.codec import count_bits
-from oracle.metrics import pc_metrics
-from _parity import assert_psnr_parity, voxel_flips
+from _parity import compare_codec
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -110,7 +108,7 @@ def test_codec_in_x3_mode_meets_the_oracle_parity_bounds(pcc, oracle_codec):
     assert not sp.INFER_X3
     sp.set_infer_x3(True)
     try:
-        for cfg in (dict(grid=32, radius=15.0, half_width=0.875), dict(grid=64, radius=27.0, half_width=0.6)):
+        for cfg in (dict(grid=32, radius=15.0, half_width=0.875), dict(grid=96, radius=40.0, half_width=0.5)):
             pts = pcc.synthetic.sphere_shell(**cfg)
             qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
             N = pts.shape[0]
@@ -120,19 +118,11 @@ def test_codec_in_x3_mode_meets_the_oracle_parity_bounds(pcc, oracle_codec):
                 Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
                 strings, shape, k, coords = model.compress(x, Q)
                 rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
-                return strings, shape, k, coords, rec
-            strings, shape, k, coords, rec = code()
-            s2, _, _, _, rec2 = code()
-            assert strings == s2 and torch.equal(rec, rec2)                      # deterministic
-            o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
-            assert shape == o_shape and k == o_k
-            bpp, o_bpp = count_bits(strings) / N, count_bits(o_strings) / N
-            assert abs(bpp - o_bpp) <= 2e-3 * o_bpp + 1e-3, (bpp, o_bpp)
-            o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
-            rec = rec.cpu().numpy()
-            flips = voxel_flips(rec, o_rec)
-            assert flips <= max(4, int(2e-3 * N)), flips
-            assert_psnr_parity(pc_metrics(pts, rec), pc_metrics(pts, o_rec), flips, N, ("x3", cfg))
+                return strings, rec
+            s1, rec = code()
+            s2, rec2 = code()
+            assert s1 == s2 and torch.equal(rec, rec2)                           # deterministic
+            compare_codec(pcc, model, oracle_codec, pts, qc, qf, ("x3", cfg), DEV)   # the fp32 codec's stage-by-stage bounds
         # encoder-side and decoder-side latents agree bit for bit in this mode too
         coords4 = torch.cat([torch.zeros((N, 1), device=DEV, dtype=torch.int32), x[:, :3].to(torch.int32)], dim=1)
         feats = torch.cat([torch.ones((N, 1), device=DEV), x[:, 3:6]], dim=1)
