@@ -66,6 +66,8 @@ class ColorModel(nn.Module):
         one count per item and stage, and ``coordinates`` carries the item index in column 0."""
         N = x.shape[0]
         dev = x.device
+        if N == 0 or x.dim() != 2 or x.shape[1] < 6:
+            raise ValueError(f"compress: expected a [N, 6] tensor (xyz voxel coordinates + rgb) with N > 0, got {tuple(x.shape)}")
         if batch is None:
             bcol = torch.zeros((N, 1), device=dev, dtype=torch.int32)
             nbatch = 1

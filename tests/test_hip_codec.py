@@ -253,6 +253,19 @@ def test_tiny_clouds(pcc, model, oracle_codec, n_pts):
     assert len(a ^ b) <= 2
 
 
+def test_grid_corners_and_empty_input(pcc, model, oracle_codec):
+    """coordinates at both ends of the 10-bit grid (neighbour probes leave the grid on every side, two unconnected latents)
+    and an empty cloud (a clear error instead of a zero-sized launch)"""
+    pts = np.array([[0, 0, 0, 0.1, 0.2, 0.3], [1023, 1023, 1023, 0.9, 0.8, 0.7], [0, 1023, 0, 0.5, 0.5, 0.5],
+                    [1023, 0, 1, 0.0, 1.0, 0.0]], np.float32)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    r = compare_codec(pcc, model, oracle_codec, pts, qc, qf, "corners", DEV)
+    assert r["flips"] == 0
+    with pytest.raises(ValueError):
+        Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+        model.compress(torch.zeros((0, 6), device=DEV), Q)
+
+
 def test_full_size_frame_properties(pcc, model):
     """BASELINE config 2 (N = 850,824), size-independent properties instead of an oracle run:
     determinism (same bytes twice, same reconstruction twice), header facts, k consistency,
