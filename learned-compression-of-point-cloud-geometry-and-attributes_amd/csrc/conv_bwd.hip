@@ -826,6 +826,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dw[e] = sum;
 }
 
+// the same sums, four elements per thread with 16-byte loads (elems % 4 == 0, 16-byte aligned partials: the MFMA shapes)
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float4* __restrict__ partial, int64_t elems4, int nsplit,
+                                                            float4* __restrict__ dw) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems4) return;
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int s = 0; s < nsplit; ++s) {                                              // fixed order
+        const float4 v = partial[(int64_t)s * elems4 + e];
+        sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+    }
+    dw[e] = sum;
+}
+
 }  // namespace pcc
 
 using namespace pcc;
@@ -847,6 +860,13 @@ int pcc_kernel_map_transpose(const int32_t* nbr, int64_t n_out, int32_t K, int64
     return PCC_OK;
 }
 
+static inline void launch_wgrad_reduce(const float* partial, int64_t elems, int nsplit, float* dw, hipStream_t st) {
+    if (elems % 4 == 0 && ((reinterpret_cast<uintptr_t>(partial) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(blocks_for(elems / 4, 256)), dim3(256), 0, st,
+                           reinterpret_cast<const float4*>(partial), elems / 4, nsplit, reinterpret_cast<float4*>(dw));
+    else
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, partial, elems, nsplit, dw);
+}
 static inline bool wgrad_mfma(int cin, int cout) { return cin % 32 == 0 && cout % 32 == 0; }
 static inline bool wgrad_rowsplit(int cin, int cout) { return wgrad_mfma(cin, cout) && cin <= 64 && cout <= 64; }
 static inline int wgrad_splits(int64_t n_out) {            // at least ~48 row groups per workgroup
@@ -933,8 +953,7 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
         PCC_REQUIRE((int64_t)cin * cout <= 4096, "pcc_conv_wgrad: thin path handles cin * cout <= 4096 (got %d x %d)", cin, cout);
         hipLaunchKernelGGL(conv_wgrad_thin_kernel, dim3((unsigned)(K * WG_SPLIT_THIN)), dim3(256), 0, st, a);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems,
-                       wgrad_partials(cin, cout, a.split, K), dw);
+    launch_wgrad_reduce(scratch, elems, wgrad_partials(cin, cout, a.split, K), dw, st);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
@@ -976,13 +995,13 @@ int pcc_conv_wgrad_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const ui
         if (slice_o == 3) hipLaunchKernelGGL(conv_wgrad_bf16_slice_kernel<3>, dim3(sets * a.split), dim3(256), lds, st, a);
         else if (slice_o == 5) hipLaunchKernelGGL(conv_wgrad_bf16_slice_kernel<5>, dim3(sets * a.split), dim3(256), lds, st, a);
         else hipLaunchKernelGGL(conv_wgrad_bf16_slice_kernel<9>, dim3(sets * a.split), dim3(256), lds, st, a);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, a.split, dw);
+        launch_wgrad_reduce(scratch, elems, a.split, dw, st);
         PCC_LAUNCH_CHECK();
         return PCC_OK;
     }
     const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
     hipLaunchKernelGGL(conv_wgrad_bf16_kernel, grid, dim3(256), 4 * 2048 * sizeof(unsigned short), st, a);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks_for(elems, 256)), dim3(256), 0, st, scratch, elems, a.split, dw);
+    launch_wgrad_reduce(scratch, elems, a.split, dw, st);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }
