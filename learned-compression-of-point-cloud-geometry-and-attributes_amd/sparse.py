@@ -377,8 +377,14 @@ def topk_mask(logits, coords, k_per_batch, nbatch):
     L = _lib.lib()
     n = logits.shape[0]
     dev = logits.device
-    k = torch.tensor([int(v) for v in k_per_batch], dtype=torch.int32, device=dev)
-    assert k.numel() == nbatch, (k.numel(), nbatch)
+    # the counts reach the device without a stream synchronisation: torch.tensor(list, device=...) copies from pageable
+    # memory, i.e. it blocks the host until everything queued before it — the candidate-level convolutions — has run
+    ks = [int(v) for v in k_per_batch]
+    assert len(ks) == nbatch, (len(ks), nbatch)
+    if nbatch == 1:
+        k = torch.full((1,), ks[0], dtype=torch.int32, device=dev)
+    else:
+        k = torch.tensor(ks, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
     state = torch.empty(L.pcc_topk_state_elems(nbatch), dtype=torch.int32, device=dev)
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
     check(L.pcc_topk_mask(ptr(logits), logits.stride(0), ptr(coords), n, nbatch, ptr(k), ptr(mask), ptr(state),
