@@ -418,16 +418,21 @@ def main():
                 raise errs[0]
             return time.perf_counter() - ts0, done
 
-        s_frames = max(4, min(12, 2 * args.steps))
-        run_stream(2, 4)                                  # per-thread warm-up (pinned staging, side streams, count words)
-        s_elapsed, s_done = run_stream(2, s_frames)
-        f32_bits = pcc_amd.utils.count_bits(last["strings"])
-        streamed_record = {"value": N * s_frames / s_elapsed / 1e6, "unit": "Mpoints/s", "frames": s_frames, "frames_in_flight": 2,
-                           "ms_per_frame": s_elapsed / s_frames * 1e3,
-                           "streams_equal_to_sequential": bool(all(d == (last["rec"].shape[0], f32_bits) for d in s_done)),
-                           "note": "whole frames, each encoded to bytes and decoded from them; a frame's latency is the sequential "
-                                   "ms_per_step or more — only the throughput of a sequence gains (BASELINE config 4's shape on "
-                                   "one GPU); the headline `value` is the one-frame-at-a-time run above"}
+        try:
+            s_frames = max(4, min(12, 2 * args.steps))
+            run_stream(2, 4)                                  # per-thread warm-up (pinned staging, side streams, count words)
+            s_elapsed, s_done = run_stream(2, s_frames)
+            f32_bits = pcc_amd.utils.count_bits(last["strings"])
+            streamed_record = {"value": N * s_frames / s_elapsed / 1e6, "unit": "Mpoints/s", "frames": s_frames, "frames_in_flight": 2,
+                               "ms_per_frame": s_elapsed / s_frames * 1e3,
+                               "streams_equal_to_sequential": bool(all(d == (last["rec"].shape[0], f32_bits) for d in s_done)),
+                               "note": "whole frames, each encoded to bytes and decoded from them; a frame's latency is the sequential "
+                                       "ms_per_step or more — only the throughput of a sequence gains (BASELINE config 4's shape on "
+                                       "one GPU); the headline `value` is the one-frame-at-a-time run above"}
+        except Exception as e:                         # a sub-record must never take the headline line down with it
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            streamed_record = {"error": repr(e)[:300]}
 
     # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
     classes = {}
