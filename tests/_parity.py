@@ -92,7 +92,8 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0")
     flips = voxel_flips(rec, o_rec)
     m = pc_metrics(pts, rec)
     if n_sym == 0:
-        assert flips <= max(4, int(2e-3 * N)), (tag, flips)
+        # more near-ties than in stage 2: here the two decoders also start from latents whose means differ in the last bits
+        assert flips <= max(8, int(5e-3 * N)), (tag, flips)
         assert_psnr_parity(m, om, flips, N, tag)                               # 1e-3 dB (+ the voxel-flip bound above)
     else:
         for key in ("sym_psnr_mse", "sym_y_psnr"):
