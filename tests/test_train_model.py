@@ -33,10 +33,19 @@ def coord_noise_b(shape, coords):
     return coord_noise(shape, c)
 
 
-def _setup(pcc):
+def _setup(pcc, geometry="sphere"):
     from pcc_amd import synthetic as syn
     model = syn.make_model(seed=0, device=DEV)
-    pts = syn.sphere_shell(**syn.CONFIG1)
+    if geometry == "sphere":
+        pts = syn.sphere_shell(**syn.CONFIG1)
+    else:
+        # irregular: a thick noisy shell plus scattered voxels (isolated rows, varied neighbour counts, sparse strided levels)
+        rng = np.random.default_rng(3)
+        p = rng.normal(0, 1, (5000, 3))
+        p = p / np.linalg.norm(p, axis=1, keepdims=True) * (18 + rng.normal(0, 1.5, (5000, 1)))
+        xyz = np.unique(np.clip(np.concatenate([p.round().astype(int) + 32, rng.integers(0, 64, (300, 3))]), 0, 63), axis=0)
+        rgb = (rng.integers(0, 256, (xyz.shape[0], 3)) / 255.0).astype(np.float32)
+        pts = np.concatenate([xyz.astype(np.float32), rgb], axis=1)
     qc, qf = syn.uniform_qmap(pts[:, :3], 0.3, 0.7)
     qf = qf.copy()
     qf[:, 0] = 0.2 + 0.6 * (pts[:, 0] - pts[:, 0].min()) / (pts[:, 0].max() - pts[:, 0].min())     # a gradient map: pooling matters
@@ -44,10 +53,11 @@ def _setup(pcc):
     return model, pts, qc, qf, lam
 
 
-def test_training_step_matches_oracle_autograd(pcc):
+@pytest.mark.parametrize("geometry", ["sphere", "irregular"])
+def test_training_step_matches_oracle_autograd(pcc, geometry):
     from pcc_amd import entropy as pe
     from pcc_amd.loss import OURS_LOSS, Loss
-    model, pts, qc, qf, lam = _setup(pcc)
+    model, pts, qc, qf, lam = _setup(pcc, geometry)
     model.train()
     coords = torch.from_numpy(qc).to(DEV)
     inp = pcc.SparseTensor(coordinates=coords, features=torch.from_numpy(pts[:, 3:]).to(DEV), device=DEV)
@@ -72,9 +82,12 @@ def test_training_step_matches_oracle_autograd(pcc):
     for key in o_parts:
         assert float(parts[key].detach()) == pytest.approx(float(o_parts[key].detach()), rel=2e-4), key
     assert out["prediction"].F.shape == (pts.shape[0], 3)
+    for pr, opr in zip(out["occ_predictions"], o_out["occ_predictions"]):      # same candidate sets at every stage
+        assert set(map(tuple, pr.C.cpu().numpy().tolist())) == set(map(tuple, opr.C.tolist()))
+    assert set(map(tuple, out["prediction"].C.cpu().numpy().tolist())) == set(map(tuple, o_out["prediction"].C.tolist()))
     checked = 0
     named = dict(model.named_parameters())
-    worst = (0.0, None)
+    worst = worst_l2 = (0.0, None)
     for name, leaf in sd.items():
         if leaf.grad is None or name not in named:
             continue
@@ -86,10 +99,20 @@ def test_training_step_matches_oracle_autograd(pcc):
             assert float(g.abs().max()) == 0.0, name
             continue
         err = float((g.cpu() - ref).abs().max()) / scale
+        l2 = float((g.cpu() - ref).norm() / ref.norm())
         worst = max(worst, (err, name))
+        worst_l2 = max(worst_l2, (l2, name))
         checked += 1
     assert checked > 150, checked
-    assert worst[0] < 5e-3, worst          # fp32 sums in different orders through ~60 layers
+    # Two fp32 implementations agree on every gradient to ~1e-5 (the sphere: 6.4e-6) UNLESS a ReLU gate flips: a pre-activation
+    # within the ~1e-7 relative difference of the two convolution outputs of zero is gated differently, and that one
+    # activation changes the gradients of its 27-neighbourhood and of everything upstream.  Measured on the irregular cloud
+    # (3.6 M activations on the stride-1 candidates alone, a couple of flips): up to 1.3 % of the largest element and 0.5 %
+    # in l2 on ~60 parameters, with forward values, losses (2e-7) and the gradients at the loss agreeing to 1e-5 and every
+    # operator exact in isolation (tests/test_train_ops.py).  The bounds below pass that and fail any wrong index or missing term.
+    assert worst_l2[0] < 2e-2 and worst[0] < 1e-1, (worst, worst_l2)
+    if geometry == "sphere":
+        assert worst[0] < 5e-3, worst      # no gate flips on this input with the current kernels (6.4e-6)
 
 
 def test_training_mode_draws_fresh_noise_and_eval_is_unchanged(pcc):
