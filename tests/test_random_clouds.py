@@ -65,3 +65,43 @@ def test_irregular_clouds_vs_oracle(pcc, model, oracle_codec, kind):
     # a per-point random q-map on the same geometry
     qf = rng.random((N, 2)).astype(np.float32)
     compare_codec(pcc, model, oracle_codec, pts, coords, qf, (kind, "random q"), DEV)
+
+
+def test_ragged_batch_of_irregular_items_vs_oracle(pcc, model, oracle_codec):
+    """the reference's batch mechanism (one compress call, per-item k and top-k, one stream pair) on items of very different
+    size and shape that overlap in (x, y, z): 1,500 scattered voxels, 270 voxels on three lines, ONE voxel, a filled block"""
+    from oracle.codec import count_bits
+    from oracle.metrics import pc_metrics
+    from _parity import assert_psnr_parity, voxel_flips
+    rng = np.random.default_rng(11)
+    items = [_cloud("scattered", rng), _cloud("lines", rng), np.array([[50, 50, 50, 0.3, 0.6, 0.9]], np.float32),
+             _cloud("filled_block", rng)]
+    pts = np.concatenate(items)
+    item = np.concatenate([np.full(len(p), i) for i, p in enumerate(items)])
+    N = pts.shape[0]
+    qf = rng.random((N, 2)).astype(np.float32)
+    qc = np.concatenate([item.reshape(-1, 1).astype(np.float32), pts[:, :3]], axis=1)
+    x = torch.from_numpy(pts).to(DEV)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    strings, shape, k, coords = model.compress(x, Q, batch=torch.from_numpy(item).to(DEV))
+    o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf, batch=item)
+    assert shape == o_shape and k == o_k and [len(stage) for stage in k] == [4, 4, 4]
+    assert k[2] == [len(p) for p in items]                                     # the finest stage keeps every item's own count
+    assert set(map(tuple, coords.cpu().numpy().tolist())) == set(map(tuple, o_coords.tolist()))
+    bits, o_bits = count_bits(strings), count_bits(o_strings)
+    assert abs(bits - o_bits) <= 3e-3 * o_bits + 64
+    rec, rec_item = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k, return_batch=True)
+    rec, rec_item = rec.cpu().numpy(), rec_item.cpu().numpy()
+    o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+    assert rec.shape == o_rec.shape == (N, 6)
+    for i, p in enumerate(items):
+        assert int((rec_item == i).sum()) == len(p)
+    o_item = oracle_codec.last_batch
+    flips = 0
+    for i, p in enumerate(items):                                              # per item: the same voxels, the same quality
+        a, b = rec[rec_item == i], o_rec[o_item == i]
+        f = voxel_flips(a, b)
+        flips += f
+        if len(p) > 1:
+            assert_psnr_parity(pc_metrics(p, a), pc_metrics(p, b), f, len(p), ("item", i))
+    assert flips <= max(8, int(5e-3 * N)), flips
