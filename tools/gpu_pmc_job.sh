@@ -5,7 +5,7 @@
 #   gpurun --timeout 900 -- "bash tools/gpu_pmc_job.sh"
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE GRBM_GUI_ACTIVE; do
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2_pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-blocks-record --no-x3-record > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/r2_pmc_$c -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-blocks-record --no-x3-record --no-streamed-record > /dev/null 2>&1
   echo "pmc $c rc=$?"
   rm -f $GRAFT_REPO_ROOT/gpurun_out/r2_pmc_$c/*.db
 done
