@@ -41,6 +41,18 @@ def split_blocks(points, block):
     return block_ids, rows
 
 
+def split_blocks_device(x, block):
+    """split_blocks for a device tensor without leaving the device: (block ids [M,3] numpy, point counts per cube (list),
+    cube index of every point (int64 device tensor)); cubes in the same lexicographic order.  The host version costs a
+    pageable copy of the coordinates and a 850 k-key argsort per frame and rank — 30 ms in front of a 22 ms encode."""
+    ids = torch.div(x[:, :3], block, rounding_mode="floor").to(torch.int64)
+    key = (ids[:, 0] << 42) | (ids[:, 1] << 21) | ids[:, 2]
+    uniq, inverse, counts = torch.unique(key, return_inverse=True, return_counts=True)       # sorted: lexicographic cubes
+    uniq_h = uniq.cpu().numpy()
+    block_ids = np.stack([(uniq_h >> 42) & 0x1FFFFF, (uniq_h >> 21) & 0x1FFFFF, uniq_h & 0x1FFFFF], axis=1)
+    return block_ids, [int(v) for v in counts.cpu().tolist()], inverse
+
+
 def assign_blocks(counts, world):
     """Greedy longest-processing-time assignment of blocks to ranks by point count.
     Returns a list (per rank) of block indices; deterministic."""
@@ -103,17 +115,24 @@ def compress_blocks(model, x, q_feats, block, rank=0, world=1, batched=True):
     time.  batched=False: one call and one unit (block index, strings, shape, k, coords8) per cube.
     """
     from .sparse import SparseTensor
-    xyz = x[:, :3].detach().cpu().numpy()
-    ids, rows = split_blocks(xyz, block)
-    parts = assign_blocks([len(r) for r in rows], world)
+    x = x.detach()
+    ids, counts, cube_of_point = split_blocks_device(x, block)
+    parts = assign_blocks(counts, world)
     units = []
     mine = parts[rank]
+
+    def rows_of(cubes):
+        """(row indices, item index per row) of the given cubes: cube after cube, original row order inside a cube"""
+        lut = torch.full((len(counts),), -1, dtype=torch.int64, device=x.device)
+        lut[torch.tensor(cubes, dtype=torch.int64, device=x.device)] = torch.arange(len(cubes), dtype=torch.int64, device=x.device)
+        item_all = lut[cube_of_point]
+        sel = torch.nonzero(item_all >= 0).flatten()
+        item, order = torch.sort(item_all[sel], stable=True)
+        return sel[order], item.to(torch.int32)
+
     if batched:
         if mine:
-            sel_np = np.concatenate([rows[b] for b in mine])
-            item = np.concatenate([np.full(len(rows[b]), i, dtype=np.int32) for i, b in enumerate(mine)])
-            sel = torch.from_numpy(sel_np).to(x.device)
-            bt = torch.from_numpy(item).to(x.device)
+            sel, bt = rows_of(list(mine))
             xb = x.index_select(0, sel)
             qc = torch.cat([bt.reshape(-1, 1).to(xb.dtype), xb[:, :3]], dim=1)
             Q = SparseTensor(coordinates=qc, features=q_feats.index_select(0, sel), device=x.device, nbatch=len(mine))
@@ -121,7 +140,7 @@ def compress_blocks(model, x, q_feats, block, rank=0, world=1, batched=True):
             units.append((list(mine), strings, shape, k, coords))
         return ids, parts, units
     for b in mine:
-        sel = torch.from_numpy(rows[b]).to(x.device)
+        sel, _ = rows_of([b])
         xb = x.index_select(0, sel)
         qc = torch.cat([torch.zeros((xb.shape[0], 1), device=x.device), xb[:, :3]], dim=1)
         Q = SparseTensor(coordinates=qc, features=q_feats.index_select(0, sel), device=x.device)

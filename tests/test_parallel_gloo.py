@@ -69,6 +69,12 @@ def test_partition_helpers(pcc):
     for bid, r in zip(ids, rows):
         assert (np.floor_divide(pts[r, :3], 32) == bid).all()
     counts = [len(r) for r in rows]
+    # the device version (what compress_blocks runs; here on CPU tensors): same cubes in the same order, same membership
+    import torch
+    ids_d, counts_d, cube_of_point = par.split_blocks_device(torch.from_numpy(pts), 32)
+    assert np.array_equal(ids_d, ids) and counts_d == counts
+    for i, r in enumerate(rows):
+        assert np.array_equal(np.nonzero(cube_of_point.numpy() == i)[0], np.sort(r))
     parts = par.assign_blocks(counts, 3)
     assert sorted(sum(parts, [])) == list(range(len(rows)))
     loads = [sum(counts[b] for b in p) for p in parts]
