@@ -158,7 +158,14 @@ def main():
     dev = torch.device("cuda", local_rank)
     cdev = torch.device("cpu") if rehearse else dev          # device of the collectives' tensors
     dist = None
-    if world > 1:
+    # PCC_BENCH_FORCE_DIST=1: take the multi-GPU branches with a world of ONE rank over `nccl` — the collectives degenerate to
+    # copies, but every RCCL call of an N-GPU run (setup, all_gather_into_tensor on uint8 / int64, all_reduce, barrier) is
+    # made on the device; a one-GPU box cannot host two ranks on one device.  Never a measurement of scaling.
+    force_dist = world == 1 and os.environ.get("PCC_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -211,7 +218,7 @@ def main():
         rec = par.decompress_blocks(model, units) if units else None
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        if world > 1:
+        if dist is not None:
             payload = b"".join(par.pack_items_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
             par.all_gather_bitstreams(payload, cdev)
         if timed:
@@ -246,7 +253,7 @@ def main():
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         mark()
-        if world > 1:
+        if dist is not None:
             gather_bitstreams(strings, shape, k)
         if timed:
             t_enc += t1 - t0
@@ -299,7 +306,7 @@ def main():
             torch.cuda.synchronize()
             rec_ = par.decompress_blocks(model, units) if units else None
             payload = b"".join(par.pack_items_unit(s_, sh, k_) for _, s_, sh, k_, _ in units)
-            if world > 1:
+            if dist is not None:
                 par.all_gather_bitstreams(payload, cdev)
             return units, parts_, (0 if rec_ is None else rec_.shape[0]), rec_
 

@@ -175,9 +175,13 @@ class GradBucketReducer:
     usage:  red = GradBucketReducer(model.parameters());  loss.backward();  red.finish();  opt.step()
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, always_reduce=False):
+        """always_reduce: issue the collectives even in a world of one rank (a process group must be up) — how a one-GPU
+        box exercises the RCCL calls of the N-GPU path; the result is unchanged (sum over one rank, divided by one)"""
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        up = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if up else 1
+        self.collective = self.world > 1 or (bool(always_reduce) and up)
         self.params = [p for p in params if p.requires_grad]
         self.buckets = []          # (flat tensor, [(param, offset, numel)])
         cur, cur_elems = [], 0
@@ -220,7 +224,7 @@ class GradBucketReducer:
                 flat[off:off + n].zero_()
             else:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
-        if self.world > 1:
+        if self.collective:
             self._works[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):

@@ -29,7 +29,12 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import torch.distributed as dist
-    if world > 1:
+    # PCC_BENCH_FORCE_DIST=1: a world of ONE rank over nccl — the gradient reducer's bucketed all-reduces, the barriers and the
+    # timing all-reduces are real RCCL calls (degenerate collectives); what a one-GPU box can exercise of the N-GPU path
+    active = world > 1 or os.environ.get("PCC_BENCH_FORCE_DIST") == "1"
+    if active:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29551")
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
     import pcc_amd
     from pcc_amd import parallel as par, synthetic as syn
@@ -44,7 +49,7 @@ def main():
     rng = random.Random(1234 + rank)
     params = [p for n, p in model.named_parameters() if not n.endswith(".quantiles")]      # train.py:63-64
     opt = torch.optim.Adam(params, lr=1e-4)
-    red = par.GradBucketReducer(params)
+    red = par.GradBucketReducer(params, always_reduce=active)
     qgen = Q_Map({"mode": "exponential", "lambda_A_max": 12800, "lambda_A_min": 100, "lambda_G_max": 1600, "lambda_G_min": 25})
     loss_fn = Loss(OURS_LOSS)
     random.seed(99 + rank)
@@ -77,7 +82,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if active:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -85,11 +90,11 @@ def main():
     for _ in range(args.steps):
         n, last = step()
         npts += n
-    if world > 1:
+    if active:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if active:
         t = torch.tensor([el, float(npts)], dtype=torch.float64, device="cpu" if rehearse else dev)
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         ts = t.clone(); dist.all_reduce(ts)
@@ -99,7 +104,7 @@ def main():
                           "ms_per_step": el / args.steps * 1e3, "batch_cubes_per_gpu": args.batch, "block": args.block,
                           "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic"}))
     feed.close()
-    if world > 1:
+    if active:
         dist.destroy_process_group()
 
 
