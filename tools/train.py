@@ -31,7 +31,10 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     import torch.distributed as dist
-    if world > 1:
+    active = world > 1 or os.environ.get("PCC_BENCH_FORCE_DIST") == "1"       # see tools/train_bench.py: a world of one rank over RCCL
+    if active:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29561")
         dist.init_process_group("nccl", rank=rank, world_size=world)
     import pcc_amd
     from pcc_amd import autograd as ag, io, parallel as par, synthetic as syn
@@ -57,10 +60,10 @@ def main():
     aux_params = [p for n, p in model.named_parameters() if n.endswith(".quantiles")]
     opt = torch.optim.Adam(params, lr=args.lr)
     aux_opt = torch.optim.Adam(aux_params, lr=args.aux_lr)
-    red = par.GradBucketReducer(params)
+    red = par.GradBucketReducer(params, always_reduce=active)
     # the bottleneck (.quantiles) parameters are averaged across ranks as well: they set the CDF tables update()
     # builds, and every rank must end up with the same tables (rank 0 alone writes the checkpoint)
-    aux_red = par.GradBucketReducer(aux_params)
+    aux_red = par.GradBucketReducer(aux_params, always_reduce=active)
     qgen = Q_Map({"mode": "exponential", "lambda_A_max": 12800, "lambda_A_min": 100, "lambda_G_max": 1600, "lambda_G_min": 25})
     loss_fn = Loss(OURS_LOSS)
     t0 = time.time()
@@ -101,7 +104,7 @@ def main():
         os.makedirs(os.path.dirname(args.out), exist_ok=True)
         torch.save(model.state_dict(), args.out)
         print("saved", args.out, flush=True)
-    if world > 1:
+    if active:
         dist.destroy_process_group()
 
 
