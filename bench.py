@@ -436,6 +436,17 @@ def main():
                                "note": "whole frames, each encoded to bytes and decoded from them; a frame's latency is the sequential "
                                        "ms_per_step or more — only the throughput of a sequence gains (BASELINE config 4's shape on "
                                        "one GPU); the headline `value` is the one-frame-at-a-time run above"}
+            if not args.no_x3_record:
+                # the same sequence with the opt-in split-bf16 products (the `split_bf16` record's arithmetic): what the
+                # fp32-class path sustains when both the range coder and a third of the matrix time are out of the way
+                sp.set_infer_x3(True)
+                try:
+                    run_stream(2, 4)
+                    sx_elapsed, _ = run_stream(2, s_frames)
+                finally:
+                    sp.set_infer_x3(False)
+                streamed_record["with_split_bf16"] = {"value": N * s_frames / sx_elapsed / 1e6, "unit": "Mpoints/s",
+                                                      "ms_per_frame": sx_elapsed / s_frames * 1e3}
         except Exception as e:                         # a sub-record must never take the headline line down with it
             import traceback
             traceback.print_exc(file=sys.stderr)
