@@ -102,6 +102,11 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
                    int32_t sign, int32_t* nbr, uint32_t* row_mask, int64_t* pair_count,
                    void* stream);
 
+/* The pair count of a kernel map from its row masks alone (sum of popcounts) — for callers that passed
+ * pair_count = NULL to pcc_kernel_map and want the figure later (FLOP accounting of a benchmark: the codec itself
+ * never reads it, so the product path does not compute it per map). */
+int pcc_pair_count(const uint32_t* row_mask, int64_t n_out, int64_t* pair_count, void* stream);
+
 /* Execution order for the MFMA convolution.  Output rows are sorted by
  * (spatial block of 2^block_log2 voxels per axis, neighbour mask); block_log2 < 0 sorts by
  * mask alone.  Rows with the same neighbour pattern become adjacent, so a 32-row MFMA tile

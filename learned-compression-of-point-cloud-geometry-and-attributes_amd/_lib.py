@@ -28,6 +28,7 @@ SIGNATURES = {
     "pcc_stride_map": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_children": (c_int, [c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_kernel_map": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_pair_count": (c_int, [c_void_p, c_i64, c_void_p, c_void_p]),
     "pcc_conv_packed_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "pcc_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "pcc_order_scratch_bytes": (c_i64, [c_i64]),

@@ -693,6 +693,17 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
     return PCC_OK;
 }
 
+int pcc_pair_count(const uint32_t* row_mask, int64_t n_out, int64_t* pair_count, void* stream) {
+    PCC_REQUIRE(pair_count != nullptr, "pcc_pair_count: no output");
+    hipStream_t st = as_stream(stream);
+    PCC_CHECK_HIP(hipMemsetAsync(pair_count, 0, sizeof(int64_t), st));
+    if (n_out <= 0) return PCC_OK;
+    hipLaunchKernelGGL(pair_count_kernel, dim3(blocks_for(n_out, 256 * 16, 512)), dim3(256), 0, st, row_mask, n_out,
+                       reinterpret_cast<unsigned long long*>(pair_count));
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
 int pcc_gather_rows(const float* src, int32_t c, const int32_t* idx, int64_t n, float* out, int32_t accumulate,
                     void* stream) {
     if (n <= 0 || c <= 0) return PCC_OK;

@@ -68,6 +68,27 @@ def _read_count(buf, device):
     return n
 
 
+class PairCount:
+    """The pair count of a kernel map (sum of the row masks' popcounts = the `pairs` of 2 * pairs * C_in * C_out), computed on
+    first use: the codec never reads it — only FLOP accounting does (bench.py's profiler, tools/) — so building a map
+    costs no reduction kernel and no memset for it.  Reads like the device scalar it used to be: .item(), int(), float()."""
+
+    def __init__(self, row_mask):
+        self._mask, self._val = row_mask, None
+
+    def item(self):
+        if self._val is None:
+            out = torch.empty(1, dtype=torch.int64, device=self._mask.device)
+            check(_lib.lib().pcc_pair_count(ptr(self._mask), self._mask.shape[0], ptr(out), _lib.stream()))
+            self._val = int(out.item())
+        return self._val
+
+    __int__ = item
+
+    def __float__(self):
+        return float(self.item())
+
+
 class CoordMap:
     """A coordinate set of one tensor stride with its hashed-voxel table and cached kernel maps.
 
@@ -147,7 +168,7 @@ class CoordMap:
         return self._cache[key]
 
     def kernel_map(self, out_map, ksize, transposed=False):
-        """(nbr int32 [N_out, K], row_mask int32 [N_out], pair_count int64[1]) for input=self, output=out_map."""
+        """(nbr int32 [N_out, K], row_mask int32 [N_out], PairCount) for input=self, output=out_map."""
         key = ("kmap", id(out_map), ksize, transposed)
         hit = self._cache.get(key)
         if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
@@ -157,10 +178,10 @@ class CoordMap:
         n_out = out_map.n
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.device)
         row_mask = torch.empty(n_out, dtype=torch.int32, device=self.device)
-        pairs = torch.empty(1, dtype=torch.int64, device=self.device)
         step = self.stride // 2 if transposed else self.stride
         check(_lib.lib().pcc_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step,
-                                        -1 if transposed else 1, ptr(nbr), ptr(row_mask), ptr(pairs), _lib.stream()))
+                                        -1 if transposed else 1, ptr(nbr), ptr(row_mask), None, _lib.stream()))
+        pairs = PairCount(row_mask)
         # keep out_map alive so its id() stays unique -- except for self (that would be a reference
         # cycle holding gigabytes of device memory until the cyclic GC runs)
         self._cache[key] = (None if out_map is self else out_map, nbr, row_mask, pairs)
