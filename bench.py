@@ -426,7 +426,7 @@ def main():
             return time.perf_counter() - ts0, done
 
         try:
-            s_frames = max(4, min(12, 2 * args.steps))
+            s_frames = max(8, min(24, 4 * args.steps))        # 20 frames by default: shorter runs vary by +- 10 % with thread timing
             run_stream(2, 4)                                  # per-thread warm-up (pinned staging, side streams, count words)
             s_elapsed, s_done = run_stream(2, s_frames)
             f32_bits = pcc_amd.utils.count_bits(last["strings"])
