@@ -2,10 +2,14 @@
 """Benchmark of the hot path: ColorModel.compress + decompress of one 10-bit frame per step.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL).  Frames are independent
-  units (the codec is intra-only), so rank r codes its own frame each step (weak scaling, no
-  data-path collective inside the codec) and the per-frame bitstreams are all-gathered over
-  RCCL at the end of every step, as a whole-sequence encoder would collect them.
+  N > 1: one rank per GPU over RCCL.  Either the driver starts the ranks (python -m torch.distributed.run ...
+  bench.py --gpus N: RANK / WORLD_SIZE are in the environment) or bench.py does it itself: with --gpus N > 1 and no
+  RANK it starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process,
+  before anything in this process has touched the GPU, relays rank 0's JSON line and exits with the child's code.  A
+  world that does not match --gpus, or fewer visible GPUs than ranks, is an error (non-zero exit), never a silent
+  one-rank run.  Frames are independent units (the codec is intra-only), so rank r codes its own frame each step (weak
+  scaling, no data-path collective inside the codec) and the per-frame bitstreams are all-gathered over RCCL at the
+  end of every step, as a whole-sequence encoder would collect them.
 
 Metric (BASELINE.json): encode+decode Mpoints/s = points coded / (t_enc + t_dec), inputs resident
 in HBM, in-memory API (strings returned; train.py:251-257), timing bracket as utils.py:448-464.
@@ -45,17 +49,77 @@ def latest_profile(stem):
     return j
 
 
+# what the dominant kernel's time and traffic depend on: the convolution kernel itself and the code that fixes its
+# execution order and kernel maps (a change there changes the gather traffic: VERDICT r2)
+KERNEL_SOURCES = ("conv.hip", "common.h", "coords.hip", "sort.hip", "sort.h", "select.hip")
+
+
 def kernel_source_sha256():
-    """hash of the sources the convolution kernels are built from: a profile taken on other sources is stale"""
+    """hash of the sources the convolution launches are built from: a profile taken on other sources is stale"""
     import hashlib
     h = hashlib.sha256()
     base = os.path.join(ROOT, "learned-compression-of-point-cloud-geometry-and-attributes_amd", "csrc")
-    for name in ("conv.hip", "common.h"):
+    for name in KERNEL_SOURCES:
         with open(os.path.join(base, name), "rb") as f:
             h.update(f.read())
     with open(os.path.join(base, "Makefile")) as f:          # the compiler flags, not the list of sources
         h.update("".join(line for line in f if line.startswith("HIPFLAGS")).encode())
     return h.hexdigest()
+
+
+def free_port():
+    """a TCP port nobody listens on right now (rendezvous of a self-launched run; fixed ports collide between
+    concurrent runs on one host)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launch_ranks(script, argv, n_gpus):
+    """`--gpus N` with N > 1 and no RANK in the environment: start the N ranks as a child process group (torchrun, one
+    rank per GPU, rendezvous on 127.0.0.1) and relay rank 0's stdout; returns the exit code for this process.  The
+    caller has not initialised the GPU (counting devices does not), and the ranks are CHILDREN, never an exec of this
+    process.  PCC_BENCH_REHEARSE=1 (every rank on cuda:0, gloo collectives — the control flow on a one-GPU box) skips the
+    device-count check; otherwise fewer visible GPUs than ranks is an error."""
+    import subprocess
+    rehearse = os.environ.get("PCC_BENCH_REHEARSE") == "1"
+    have = torch.cuda.device_count()
+    if not rehearse and have < n_gpus:
+        print(f"{os.path.basename(script)}: --gpus {n_gpus} needs {n_gpus} visible GPUs, this host shows {have}; refusing to "
+              f"run fewer ranks than asked for (PCC_BENCH_REHEARSE=1 rehearses the control flow with every rank on cuda:0 "
+              f"over gloo — never a measurement)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("PCC_BENCH_FORCE_DIST", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    print(f"[launch] {' '.join(cmd)}", file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    line = next((ln for ln in reversed(lines) if ln.lstrip().startswith("{")), None)
+    for ln in lines:
+        if ln is not line:
+            print(ln, file=sys.stderr)
+    if r.returncode != 0 or line is None:
+        print(f"[launch] the {n_gpus}-rank run failed (exit code {r.returncode}, "
+              f"{'no result line' if line is None else 'result line present'})", file=sys.stderr, flush=True)
+        return r.returncode or 3
+    print(line, flush=True)
+    return 0
+
+
+def rank_devices(dist, dev, world, rehearse):
+    """what every rank runs on, all-gathered: the `rccl` record of the result line (proof that N ranks on N devices ran)"""
+    p = torch.cuda.get_device_properties(dev)
+    mine = {"rank": int(os.environ.get("RANK", "0")), "device": str(dev), "name": p.name,
+            "pci_bus_id": getattr(p, "pci_bus_id", None), "pid": os.getpid()}
+    if dist is None:
+        return {"world": 1, "backend": None, "devices": [mine]}
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    return {"world": world, "backend": "gloo (rehearsal: every rank on cuda:0)" if rehearse else "nccl (RCCL)",
+            "devices": got}
 
 
 def parse():
@@ -65,7 +129,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "mid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", default="256,100,0.5", help="grid,radius,half_width of the CPU-baseline shell")
+    ap.add_argument("--cpu-sample", default="1024,260,0.5",
+                    help="grid,radius,half_width of the CPU-baseline shell.  Default: the config-2 frame itself (N = 850,824: "
+                         "~2.5 minutes on 16 host cores), so cpu_baseline and cpu_baseline.parity are on the headline workload; "
+                         "256,100,0.5 is a bounded 125,672-point sample (~20 s)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--partition", default="frames", choices=["frames", "blocks"],
                     help="N > 1 sharding: one frame per rank (weak scaling, the default) or the cubes of ONE frame "
@@ -144,11 +211,19 @@ def cpu_baseline(model, state_dict, sample, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # nothing in this process has touched the GPU yet: become the launcher of the N ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    if world != args.gpus:
+        print(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus}: start exactly one rank per GPU "
+              f"(python bench.py --gpus N launches them itself)", file=sys.stderr, flush=True)
+        sys.exit(2)
+    if not torch.cuda.is_available():
+        print("bench.py needs MI355X GPUs (torch.cuda.is_available() is False)", file=sys.stderr, flush=True)
+        sys.exit(2)
     # PCC_BENCH_REHEARSE=1: rehearse the N > 1 control flow on a one-GPU box — every rank on cuda:0,
     # collectives over gloo on host tensors (never a measurement)
     rehearse = os.environ.get("PCC_BENCH_REHEARSE") == "1"
@@ -171,6 +246,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    rccl = rank_devices(dist, dev, world, rehearse)
 
     import pcc_amd
     from pcc_amd import sparse as sp
@@ -592,6 +668,7 @@ def main():
         "bpp": bpp,
         "conv_gflop_per_step": sum(c["flops"] for c in classes.values()) / args.steps / 1e9,
         "roofline": roofline,
+        "rccl": rccl,
     }
     if blocks_record is not None:
         out["blocks"] = blocks_record

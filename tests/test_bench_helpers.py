@@ -30,3 +30,35 @@ def test_kernel_source_hash_tracks_the_convolution_sources(tmp_path):
         import pytest
         pytest.skip("profiles/*_traffic_dominant_kernel.json was taken on other kernel sources: bench.py reports "
                     "kernel_source_unchanged_since = false until the --pmc passes are re-taken (tools/pmc_traffic.py)")
+
+
+def _bench(args, env_extra):
+    import subprocess
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update({k: v for k, v in env_extra.items()})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True,
+                          text=True, timeout=300)
+
+
+def test_bench_never_runs_fewer_ranks_than_asked_for():
+    """`python bench.py --gpus N` either runs N ranks or exits non-zero with a message.  No GPU in this
+    container, so every route must refuse: the self-launcher (0 visible GPUs), a launcher world that does not match --gpus,
+    and — with the rehearsal switch — the started ranks themselves (their failure is relayed as the exit code)."""
+    r = _bench(["--gpus", "2"], {})
+    assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and not r.stdout.strip()
+    r = _bench(["--gpus", "4"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus 4" in r.stderr and not r.stdout.strip()
+    import torch
+    if not torch.cuda.is_available():
+        r = _bench(["--gpus", "2", "--workload", "config1", "--steps", "1", "--warmup", "0"], {"PCC_BENCH_REHEARSE": "1"})
+        assert r.returncode != 0 and "[launch]" in r.stderr and "nproc-per-node=2" in r.stderr and not r.stdout.strip()
+        assert "needs MI355X GPUs" in r.stderr                       # printed by the two ranks the launcher started
+
+
+def test_kernel_source_hash_covers_the_coordinate_side_too():
+    """the replayed HBM-traffic figure depends on the execution order (coords.hip / sort.hip / select.hip) as well as on
+    the convolution kernel: all of them are in the staleness stamp"""
+    import bench
+    assert {"conv.hip", "common.h", "coords.hip", "sort.hip", "select.hip", "sort.h"} <= set(bench.KERNEL_SOURCES)

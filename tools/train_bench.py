@@ -4,8 +4,11 @@ step, Adam, data-parallel gradient averaging over RCCL).  fp32 by default; PCC_T
 convolutions (forward, backward-data, weight gradient) on bf16 operands with fp32 accumulation.  Synthetic data: the config-2 shell cut into 128^3 cubes
 (data/datasets/full_128), colours as in bench.py; seeded weights.
 
-  python tools/train_bench.py [--batch 8] [--steps 5] [--warmup 2] [--block 128]
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py ...
+  python tools/train_bench.py [--gpus N] [--batch 8] [--steps 5] [--warmup 2] [--block 128]
+  --gpus N > 1 without RANK in the environment starts the N ranks itself (bench.launch_ranks: a torchrun child process,
+  one rank per GPU, before this process touches the GPU); under an external launcher
+  (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/train_bench.py --gpus N ...)
+  WORLD_SIZE must equal --gpus.
 """
 import argparse, json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,11 +20,20 @@ import numpy as np, torch
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs; default: WORLD_SIZE of the launcher, else 1")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--block", type=int, default=128)
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        from bench import launch_ranks
+        sys.exit(launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if int(os.environ.get("WORLD_SIZE", 1)) != args.gpus:
+        print(f"train_bench.py: WORLD_SIZE={os.environ.get('WORLD_SIZE', 1)} but --gpus {args.gpus}", file=sys.stderr, flush=True)
+        sys.exit(2)
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     rehearse = os.environ.get("PCC_BENCH_REHEARSE") == "1"      # one-GPU rehearsal of the N > 1 control flow: gloo, every rank on cuda:0
     if rehearse:
@@ -36,6 +48,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29551")
         dist.init_process_group("gloo" if rehearse else "nccl", rank=rank, world_size=world)
+    from bench import rank_devices
+    rccl = rank_devices(dist if active else None, torch.device(dev), world, rehearse)
     import pcc_amd
     from pcc_amd import parallel as par, synthetic as syn
     from pcc_amd.loss import OURS_LOSS, Loss
@@ -102,7 +116,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "training points/sec", "value": npts / el, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                           "ms_per_step": el / args.steps * 1e3, "batch_cubes_per_gpu": args.batch, "block": args.block,
-                          "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic"}))
+                          "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic", "rccl": rccl}))
     feed.close()
     if active:
         dist.destroy_process_group()
