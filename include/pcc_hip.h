@@ -55,6 +55,16 @@ int pcc_device_name(int dev, char* out, int out_len);
  * ------------------------------------------------------------------------------------- */
 int64_t pcc_hash_capacity(int64_t n);
 
+/* Coordinate range.  A voxel key has 16 bits per field: coordinates must satisfy |c| <= PCC_COORD_LIMIT and batch
+ * indices 0 <= b <= PCC_BATCH_LIMIT (the reference's radix-1e5 keys, model/blocks.py:118 and utils.py:170, take larger
+ * grids; 10- to 14-bit voxelisations fit).  A set with a coordinate outside the range is never hashed with an aliased
+ * key: pcc_stride_map / pcc_children check the source rows and every generated coordinate and report
+ * *out_count = PCC_COUNT_ERR_RANGE instead of a row count — the error reaches the host with the one value it reads
+ * anyway, at no extra synchronisation (the Python side raises ValueError). */
+#define PCC_COORD_LIMIT 32000
+#define PCC_BATCH_LIMIT 32766
+#define PCC_COUNT_ERR_RANGE (-2)
+
 /* Insert rows 0..n-1; table value = row index.  Duplicate coordinates keep the smallest
  * row index and increment *dup_count (device int32, may be NULL). */
 int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* vals, int64_t cap,
@@ -73,7 +83,8 @@ int64_t pcc_scan_scratch_elems(int64_t m);
  * (ME stride map; model/transforms.py:49-51, model/blocks.py:203,
  * model/entropy_models.py:276,280, model/model.py:189-190):
  * unique floor(c / 2ts) * 2ts, in order of first appearance.  out_coords has room for n
- * rows; *out_count (device int64) receives the number of unique rows.  On return
+ * rows; *out_count (device int64) receives the number of unique rows, or
+ * PCC_COUNT_ERR_RANGE if a source or output coordinate is outside the key range.  On return
  * (keys, vals, cap) is the hash table of the OUTPUT set (cap >= pcc_hash_capacity(n)). */
 int pcc_stride_map(const int32_t* coords, int64_t n, int32_t ts, uint64_t* keys, int32_t* vals,
                    int64_t cap, int32_t* scratch, int32_t* out_coords, int64_t* out_count,

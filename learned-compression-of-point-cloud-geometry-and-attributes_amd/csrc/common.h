@@ -39,9 +39,21 @@ static inline unsigned blocks_for(int64_t n, int per_block, unsigned cap = 0x7ff
 
 // ---- voxel key: (b << 48) | (x+2^15) << 32 | (y+2^15) << 16 | (z+2^15).
 // Ascending key order == lexicographic (b, x, y, z): the reference's canonical order
-// (utils.py:170-171).  Valid for |coord| < 32767, 0 <= b < 32767.
+// (utils.py:170-171).  16 bits per field: valid for |coord| <= COORD_LIMIT and 0 <= b <= BATCH_LIMIT — the margin below
+// 2^15 keeps every neighbour probe (coordinate +- one step of a tensor stride <= 512) inside the field, so a key never
+// wraps onto another voxel's.  The reference's radix-1e5 keys (model/blocks.py:118, utils.py:170) take larger grids;
+// here a coordinate outside the range is an ERROR reported with the row count of the next coordinate-set
+// construction (coords.hip: unique_insert -> COUNT_ERR_RANGE), never an aliased key.
 constexpr uint64_t KEY_EMPTY = 0xFFFFFFFFFFFFFFFFull;
 constexpr int COORD_BIAS = 1 << 15;
+constexpr int COORD_LIMIT = 32000;
+constexpr int BATCH_LIMIT = 32766;
+constexpr int64_t COUNT_ERR_RANGE = -2;      // written instead of a row count (PCC_COUNT_ERR_RANGE in pcc_hip.h)
+
+__host__ __device__ __forceinline__ bool coord_in_range(int b, int x, int y, int z) {
+    return (unsigned)b <= (unsigned)BATCH_LIMIT && (unsigned)(x + COORD_LIMIT) <= 2u * COORD_LIMIT &&
+           (unsigned)(y + COORD_LIMIT) <= 2u * COORD_LIMIT && (unsigned)(z + COORD_LIMIT) <= 2u * COORD_LIMIT;
+}
 
 __host__ __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
     return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)(x + COORD_BIAS) << 32) |
@@ -84,15 +96,25 @@ __host__ __device__ __forceinline__ int grid_shift_of(int tensor_stride) {      
     return s;
 }
 
-// Probe the table.  Returns row id or -1.
+// Probe the table.  Returns row id or -1.  A key's lane (every 8th slot from its first one) is searched first; only if that
+// whole lane holds other keys — which needs more than a quarter of a set's voxels in one lane: adversarial input — the
+// search goes on slot by slot from the first slot, exactly as table_claim (coords.hip) placed the key.  Lanes only ever
+// fill, so "the lane is full" reads the same for the insert and for every later lookup.
 __device__ __forceinline__ int table_find(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                           uint64_t mask, int shift, uint64_t key) {
-    uint64_t slot = table_slot0(key, mask, shift);
+    const uint64_t slot0 = table_slot0(key, mask, shift);
+    uint64_t slot = slot0;
     for (uint64_t probe = 0; probe <= mask; probe += TABLE_PROBE_STEP) {
         const uint64_t k = keys[slot];
         if (k == key) return vals[slot];
         if (k == KEY_EMPTY) return -1;
         slot = (slot + TABLE_PROBE_STEP) & mask;
+    }
+    for (uint64_t probe = 1; probe <= mask; ++probe) {          // cold: the key's lane is full
+        slot = (slot0 + probe) & mask;
+        const uint64_t k = keys[slot];
+        if (k == key) return vals[slot];
+        if (k == KEY_EMPTY) return -1;
     }
     return -1;
 }

@@ -70,8 +70,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_sums(const int32_t* __r
     if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+// `err` (optional): a device word the producers of the flags set when the set cannot be built (unique_insert: a
+// coordinate outside the key range); the count that goes to the host is then COUNT_ERR_RANGE instead of a row count,
+// so the error travels with the one value the host reads anyway.
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_of_block_sums(int32_t* __restrict__ block_sums, int64_t nb,
-                                                                 int64_t* __restrict__ total_out) {
+                                                                 int64_t* __restrict__ total_out,
+                                                                 const int32_t* __restrict__ err) {
     __shared__ int carry_s;
     if (threadIdx.x == 0) carry_s = 0;
     __syncthreads();
@@ -86,7 +90,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_of_block_sums(int32_t* __rest
         if (threadIdx.x == 0) carry_s = carry + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && total_out) *total_out = (int64_t)carry_s;
+    if (threadIdx.x == 0 && total_out) {
+        *total_out = (err && *err) ? COUNT_ERR_RANGE : (int64_t)carry_s;
+        __threadfence_system();          // the word may be page-locked host memory that the host polls
+    }
 }
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_apply(const int32_t* __restrict__ flags, int64_t m,
@@ -113,14 +120,14 @@ int64_t scan_block_sums_elems(int64_t m) { return (m + SCAN_TILE - 1) / SCAN_TIL
 
 // flags and pos may alias (in-place).  block_sums: scan_block_sums_elems(m) ints.
 int scan_flags(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total, int inclusive,
-               hipStream_t st) {
+               hipStream_t st, const int32_t* err) {
     const int64_t nb = (m + SCAN_TILE - 1) / SCAN_TILE;
     if (m <= 0) {
         if (total) PCC_CHECK_HIP(hipMemsetAsync(total, 0, sizeof(int64_t), st));
         return PCC_OK;
     }
     hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums);
-    hipLaunchKernelGGL(scan_of_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sums, nb, total);
+    hipLaunchKernelGGL(scan_of_block_sums, dim3(1), dim3(SCAN_BLOCK), 0, st, block_sums, nb, total, err);
     hipLaunchKernelGGL(scan_apply, dim3((unsigned)nb), dim3(SCAN_BLOCK), 0, st, flags, m, block_sums, pos, inclusive);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
@@ -128,22 +135,27 @@ int scan_flags(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sum
 
 static int exclusive_scan(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total,
                           hipStream_t st) {
-    return scan_flags(flags, m, pos, block_sums, total, 0, st);
+    return scan_flags(flags, m, pos, block_sums, total, 0, st, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
 // hash table
 // ---------------------------------------------------------------------------------------------
-__global__ void table_clear(uint64_t* __restrict__ keys, int32_t* __restrict__ vals, int64_t cap) {
+__global__ void table_clear(uint64_t* __restrict__ keys, int32_t* __restrict__ vals, int64_t cap, int32_t* __restrict__ err) {
+    if (err && blockIdx.x == 0 && threadIdx.x == 0) *err = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (int64_t)gridDim.x * blockDim.x) {
         keys[i] = KEY_EMPTY;
         vals[i] = 0x7fffffff;
     }
 }
 
-// claim (or find) the slot of `key`; returns slot index
+// claim (or find) the slot of `key`; returns slot index.  The key's lane first (every 8th slot); a lane that is full of
+// other keys — more than cap / 8 >= a quarter of the candidates in one lane: improbable, not impossible — hands the key
+// to slot-by-slot probing from its first slot, which table_find mirrors.  With cap >= 2 * candidates a free slot exists,
+// so the second loop always returns; mask + 1 is unreachable and callers still guard it.
 __device__ __forceinline__ uint64_t table_claim(uint64_t* keys, uint64_t mask, int shift, uint64_t key) {
-    uint64_t slot = table_slot0(key, mask, shift);
+    const uint64_t slot0 = table_slot0(key, mask, shift);
+    uint64_t slot = slot0;
     for (uint64_t probe = 0; probe <= mask; probe += TABLE_PROBE_STEP) {
         uint64_t cur = keys[slot];
         if (cur == KEY_EMPTY) {
@@ -154,12 +166,23 @@ __device__ __forceinline__ uint64_t table_claim(uint64_t* keys, uint64_t mask, i
         if (cur == key) return slot;
         slot = (slot + TABLE_PROBE_STEP) & mask;
     }
-    return mask + 1;  // lane full: cannot happen with cap >= 2 * candidates spread over the 8 lanes by (z / stride) & 7
+    for (uint64_t probe = 1; probe <= mask; ++probe) {
+        slot = (slot0 + probe) & mask;
+        uint64_t cur = keys[slot];
+        if (cur == KEY_EMPTY) {
+            cur = (uint64_t)atomicCAS((unsigned long long*)&keys[slot], (unsigned long long)KEY_EMPTY,
+                                      (unsigned long long)key);
+            if (cur == KEY_EMPTY) return slot;
+        }
+        if (cur == key) return slot;
+    }
+    return mask + 1;
 }
 
 // Candidate generators ------------------------------------------------------------------------
 struct GenRows {  // candidate i = row i
     const int32_t* coords;
+    __device__ __forceinline__ bool in_range(int64_t) const { return true; }
     __device__ __forceinline__ void get(int64_t i, int& b, int& x, int& y, int& z) const {
         const int4 c = reinterpret_cast<const int4*>(coords)[i];
         b = c.x; x = c.y; y = c.z; z = c.w;
@@ -168,6 +191,10 @@ struct GenRows {  // candidate i = row i
 struct GenStride {  // candidate i = floor(row i / 2ts) * 2ts
     const int32_t* coords;
     int s2;  // 2 * ts (power of two in practice, but do a true floor division)
+    __device__ __forceinline__ bool in_range(int64_t i) const {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        return coord_in_range(c.x, c.y, c.z, c.w);
+    }
     __device__ __forceinline__ int fl(int v) const {
         int q = v / s2;
         if ((v % s2) != 0 && v < 0) --q;
@@ -182,6 +209,7 @@ struct GenChildren {  // ks=3: candidate i = (parent i / 27, offset i % 27); ks=
     const int32_t* coords;
     int64_t n;
     int ks, half;
+    __device__ __forceinline__ bool in_range(int64_t) const { return true; }     // a child is within half a stride of its parent
     __device__ __forceinline__ void get(int64_t i, int& b, int& x, int& y, int& z) const {
         int64_t p;
         int k;
@@ -197,21 +225,30 @@ struct GenChildren {  // ks=3: candidate i = (parent i / 27, offset i % 27); ks=
 template <class Gen>
 __global__ __launch_bounds__(256) void unique_insert(Gen gen, int64_t m, uint64_t* __restrict__ keys,
                                                      int32_t* __restrict__ vals, uint64_t mask, int shift,
-                                                     int32_t* __restrict__ slot_of) {
+                                                     int32_t* __restrict__ slot_of, int32_t* __restrict__ err) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     int b, x, y, z;
     gen.get(i, b, x, y, z);
+    // the source row's own coordinates are covered too: |floor(c / 2ts) 2ts| >= |c| - 2ts + 1 and a child is within ts of
+    // its parent, so a source coordinate beyond the limit by more than a stride puts its candidate beyond it as well —
+    // and GenStride / GenChildren check the source row directly (in_range)
+    if (!coord_in_range(b, x, y, z) || !gen.in_range(i)) {
+        *err = 1;
+        slot_of[i] = (int32_t)(mask + 1);
+        return;
+    }
     const uint64_t slot = table_claim(keys, mask, shift, pack_key(b, x, y, z));
     slot_of[i] = (int32_t)slot;
     if (slot <= mask) atomicMin(&vals[slot], (int32_t)i);
 }
 
-__global__ __launch_bounds__(256) void unique_flag(int64_t m, const int32_t* __restrict__ vals,
+__global__ __launch_bounds__(256) void unique_flag(int64_t m, const int32_t* __restrict__ vals, uint32_t mask,
                                                    const int32_t* __restrict__ slot_of, int32_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
-    flags[i] = (vals[slot_of[i]] == (int32_t)i) ? 1 : 0;
+    const uint32_t slot = (uint32_t)slot_of[i];
+    flags[i] = (slot <= mask && vals[slot] == (int32_t)i) ? 1 : 0;       // slot > mask: the candidate was rejected (range error)
 }
 
 // incl = inclusive scan of the winner flags: candidate i won its slot iff the scan steps at i, and its output row
@@ -239,18 +276,21 @@ static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int6
     PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0, "hash capacity %lld is not a power of two", (long long)cap);
     PCC_REQUIRE(cap >= 2 * m, "hash capacity %lld too small for %lld candidates", (long long)cap, (long long)m);
     PCC_REQUIRE(m < (1ll << 31) - 1, "too many candidates (%lld)", (long long)m);
-    hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap);
+    PCC_REQUIRE(cap <= (1ll << 31), "hash capacity %lld exceeds 2^31 slots", (long long)cap);
+    int32_t* slot_of = scratch;
+    int32_t* flags = scratch + (m > 0 ? m : 0);
+    int32_t* block_sums = scratch + 2 * (m > 0 ? m : 0);
+    // the error word lives in the 16 spare ints behind the scan's block sums (pcc_scan_scratch_elems); table_clear zeroes it
+    int32_t* err = block_sums + (m > 0 ? (m + SCAN_TILE - 1) / SCAN_TILE : 0) + 8;
+    hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap, err);
     if (m <= 0) {
         PCC_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int64_t), st));
         return PCC_OK;
     }
-    int32_t* slot_of = scratch;
-    int32_t* flags = scratch + m;
-    int32_t* block_sums = scratch + 2 * m;
     const unsigned nb = blocks_for(m, 256);
-    hipLaunchKernelGGL(unique_insert<Gen>, dim3(nb), dim3(256), 0, st, gen, m, keys, vals, (uint64_t)(cap - 1), shift, slot_of);
-    hipLaunchKernelGGL(unique_flag, dim3(nb), dim3(256), 0, st, m, vals, slot_of, flags);
-    int rc = scan_flags(flags, m, flags, block_sums, out_count, 1, st);
+    hipLaunchKernelGGL(unique_insert<Gen>, dim3(nb), dim3(256), 0, st, gen, m, keys, vals, (uint64_t)(cap - 1), shift, slot_of, err);
+    hipLaunchKernelGGL(unique_flag, dim3(nb), dim3(256), 0, st, m, vals, (uint32_t)(cap - 1), slot_of, flags);
+    int rc = scan_flags(flags, m, flags, block_sums, out_count, 1, st, err);
     if (rc) return rc;
     hipLaunchKernelGGL(unique_finalize<Gen>, dim3(nb), dim3(256), 0, st, gen, m, vals, slot_of, flags, out_coords);
     PCC_LAUNCH_CHECK();
@@ -380,77 +420,6 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     __syncthreads();
     if (row_mask && threadIdx.x < nrows) row_mask[row0 + threadIdx.x] = rm[threadIdx.x];
     if (threadIdx.x == 0 && pair_count && !row_mask && hits_s) atomicAdd(pair_count, (unsigned long long)hits_s);
-}
-
-// Variant with wave = (dx, dy) column, lane = output row (one 576-thread block per 64 rows): a thread probes its
-// column's three dz targets with the three first-slot loads in flight together and the table tile is assembled in
-// LDS.  Measured SLOWER than the offset-fastest mapping on MI355X (5.16 M-row candidate set: 2.0 ms against
-// 1.35 ms): a wave instruction here touches 64 different lines, the offset-fastest one ~25 — the three dz lanes
-// of a column and the 27 lanes of a row coalesce.  Kept for A/B runs (PCC_KMAP_VARIANT=column).
-template <bool POW2>
-__global__ __launch_bounds__(576) void kernel_map3_kernel(const int32_t* __restrict__ out_coords, int64_t n_out,
-                                                          const uint64_t* __restrict__ keys,
-                                                          const int32_t* __restrict__ vals, uint64_t mask, int shift,
-                                                          int step, int parent_pitch, int32_t* __restrict__ nbr,
-                                                          uint32_t* __restrict__ row_mask,
-                                                          unsigned long long* __restrict__ pair_count) {
-    __shared__ int32_t tile[64 * 27];
-    __shared__ unsigned rm[64];
-    const int lane = threadIdx.x & 63, col = threadIdx.x >> 6;       // col = (dx + 1) + 3 (dy + 1)
-    const int64_t row0 = (int64_t)blockIdx.x * 64;
-    const int64_t r = row0 + lane;
-    if (threadIdx.x < 64) rm[threadIdx.x] = 0u;
-    __syncthreads();
-    int idx[3] = {-1, -1, -1};
-    if (r < n_out) {
-        const int4 c = reinterpret_cast<const int4*>(out_coords)[r];
-        const int dx = col % 3 - 1, dy = col / 3 - 1;
-        const int x = c.y + dx * step, y = c.z + dy * step;
-        // transposed maps: a parent exists only on the grid of pitch parent_pitch (= 2 |step|)
-        auto off_grid = [&](int v) { return parent_pitch > 0 && (POW2 ? (v & (parent_pitch - 1)) != 0 : (v % parent_pitch) != 0); };
-        if (!off_grid(x) && !off_grid(y)) {
-            uint64_t key[3], slot[3], q[3];
-            bool live[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int z = c.w + (j - 1) * step;
-                live[j] = !off_grid(z);
-                key[j] = pack_key(c.x, x, y, z);
-                slot[j] = table_slot0(key[j], mask, shift);
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) q[j] = live[j] ? keys[slot[j]] : KEY_EMPTY;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                // continue along the lane only on a collision (rare at load <= 1/2)
-                for (uint64_t probe = 0; q[j] != key[j] && q[j] != KEY_EMPTY && probe <= mask; probe += TABLE_PROBE_STEP) {
-                    slot[j] = (slot[j] + TABLE_PROBE_STEP) & mask;
-                    q[j] = keys[slot[j]];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) idx[j] = (q[j] == key[j]) ? vals[slot[j]] : -1;
-        }
-    }
-    unsigned bits = 0u;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        tile[lane * 27 + 9 * j + col] = idx[j];                       // stride 27 words: conflict-free
-        bits |= (idx[j] >= 0) ? (1u << (9 * j + col)) : 0u;
-    }
-    if (bits) atomicOr(&rm[lane], bits);
-    __syncthreads();
-    const int rows = (int)((n_out - row0 < 64) ? (n_out - row0) : 64);
-    int32_t* dst = nbr + row0 * 27;
-    for (int e = threadIdx.x; e < rows * 27; e += 576) dst[e] = tile[e];
-    if (threadIdx.x < 64) {
-        const unsigned m = (threadIdx.x < rows) ? rm[threadIdx.x] : 0u;
-        if (row_mask && threadIdx.x < rows) row_mask[row0 + threadIdx.x] = m;
-        int hits = __popc(m);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) hits += __shfl_xor(hits, d, 64);
-        if (threadIdx.x == 0 && pair_count && !row_mask && hits) atomicAdd(pair_count, (unsigned long long)hits);
-    }
 }
 
 // pairs = sum of popcount(row_mask).  A separate grid-stride reduction with a few hundred workgroups: one atomic per
@@ -609,7 +578,7 @@ int pcc_hash_build(const int32_t* coords, int64_t n, uint64_t* keys, int32_t* va
     const int shift = grid_shift_of(tensor_stride);
     PCC_REQUIRE(cap > 0 && (cap & (cap - 1)) == 0 && cap >= 2 * n, "pcc_hash_build: bad capacity %lld for n=%lld",
                 (long long)cap, (long long)n);
-    hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap);
+    hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap, (int32_t*)nullptr);
     if (dup_count) PCC_CHECK_HIP(hipMemsetAsync(dup_count, 0, sizeof(int32_t), st));
     if (n > 0) {
         hipLaunchKernelGGL(build_insert, dim3(blocks_for(n, 256)), dim3(256), 0, st, coords, n, keys, vals,
@@ -662,10 +631,10 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
     // the input set's grid: pitch `step` for a (strided) convolution, 2 * step for a transposed one
     const int in_stride = sign > 0 ? step : 2 * step;
     const int pitch = sign > 0 ? 0 : 2 * step;
-    static int variant = -1;      // PCC_KMAP_VARIANT=generic|column: A/B switches (tools/kmap_bench.py); default = offset-fastest, K = 27
-    if (variant < 0) {
-        const char* e = getenv("PCC_KMAP_VARIANT");
-        variant = !e ? 0 : (e[0] == 'g' ? 1 : (e[0] == 'c' ? 2 : 0));
+    static int variant = -1;      // PCC_KMAP_VARIANT=generic: A/B switch; default = offset-fastest, K = 27.  (A wave-per-(dx, dy)-column
+    if (variant < 0) {            // variant measured 2.0 ms against 1.35 ms on the 5.16 M-row set — a wave instruction touched 64
+        const char* e = getenv("PCC_KMAP_VARIANT");      // different lines instead of ~25 — and was removed in round 3.)
+        variant = !e ? 0 : (e[0] == 'g' ? 1 : 0);
     }
     const bool pow2 = pitch == 0 || (pitch & (pitch - 1)) == 0;
     unsigned long long* pc = reinterpret_cast<unsigned long long*>(pair_count);
@@ -677,11 +646,6 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
         if (pow2) hipLaunchKernelGGL(kernel_map27_kernel<true>, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
                                      sign * step, pitch, nbr, row_mask, pc);
         else hipLaunchKernelGGL(kernel_map27_kernel<false>, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
-                                sign * step, pitch, nbr, row_mask, pc);
-    } else if (ksize == 3 && variant == 2) {
-        if (pow2) hipLaunchKernelGGL(kernel_map3_kernel<true>, dim3(nb), dim3(576), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
-                                     sign * step, pitch, nbr, row_mask, pc);
-        else hipLaunchKernelGGL(kernel_map3_kernel<false>, dim3(nb), dim3(576), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
                                 sign * step, pitch, nbr, row_mask, pc);
     } else {
         hipLaunchKernelGGL(kernel_map_kernel, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift, ksize, K,

@@ -10,10 +10,11 @@ static inline int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 
 // --- scans (coords.hip) -----------------------------------------------------------------------------
 // pos[i] = sum of flags[0..i) (exclusive) or flags[0..i] (inclusive != 0); flags and pos may alias.
-// block_sums: scan_block_sums_elems(m) ints of scratch.  *total (device int64, may be NULL) = sum of all flags.
+// block_sums: scan_block_sums_elems(m) ints of scratch.  *total (device int64, may be NULL) = sum of all flags — or
+// COUNT_ERR_RANGE when `err` (device int32, optional) is non-zero by the time the block sums are scanned.
 int64_t scan_block_sums_elems(int64_t m);
 int scan_flags(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sums, int64_t* total, int inclusive,
-               hipStream_t st);
+               hipStream_t st, const int32_t* err = nullptr);
 
 // --- radix sort (sort.hip) --------------------------------------------------------------------------
 // Sorts n pairs by bits [begin_bit, end_bit) of the key, ascending, stable.  keys_a / vals_a hold the input and

@@ -54,15 +54,31 @@ def _host_count():
     return hit[0]
 
 
+class CoordinateRangeError(ValueError):
+    """a coordinate outside the voxel key's range (|c| <= 32000, 0 <= batch index <= 32766: include/pcc_hip.h)"""
+
+
+COUNT_ARMED, COUNT_ERR_RANGE = -1, -2            # PCC_COUNT_ERR_RANGE of include/pcc_hip.h
+
+
 def _read_count(buf, device):
+    """The row count the scan kernel wrote into this thread's page-locked word.  A short poll (the kernel that writes it
+    runs ahead of the row movers, so the word usually lands while the host is still here), yielding the interpreter lock
+    between reads so that the other coding threads of a streamed run are not starved; then a real wait on the stream,
+    which releases the lock for its whole duration."""
     import time
     arr = _COUNT_BUFS[__import__("threading").get_ident()][1]
     deadline = time.perf_counter() + 2e-3
-    while arr[0] < 0:
+    while arr[0] == COUNT_ARMED:
         if time.perf_counter() > deadline:        # not visible yet (or the stream is behind): fall back to a real wait
             torch.cuda.current_stream(device).synchronize()
             break
+        time.sleep(0)
     n = int(arr[0])
+    if n == COUNT_ERR_RANGE:
+        raise CoordinateRangeError("libpcc_hip: a voxel coordinate is outside the supported range (|c| <= 32000, batch index "
+                                   "<= 32766): the 16-bit fields of the voxel key would alias — re-voxelise to <= 14 bits or "
+                                   "translate the cloud towards the origin")
     if n < 0:
         raise RuntimeError("libpcc_hip: the row count was never written (kernel failure?)")
     return n
@@ -518,6 +534,12 @@ def set_infer_x3(enabled):
     INFER_X3 = bool(enabled)
 
 
+# Optional activation probe of the training path (tests/test_train_model.py): a list that receives (layer module, output
+# coordinates, gate = pre-activation > 0) for every activated convolution of a training-mode forward, so that the gradient
+# comparison with the oracle can differentiate both sides through the same ReLU gates.
+GATE_LOG = None
+
+
 # Optional launch log for bench.py: a list that receives one tuple per convolution launch
 # (kernel class, cin, cout, pairs (device scalar or int), n_out, start event, end event).  The
 # events are recorded on the stream the kernel is launched on (torch's current stream).
@@ -664,6 +686,10 @@ class _ConvBase(nn.Module):
             # residual — in the order the fused inference epilogue applies them) a second one (csrc/epilogue.hip)
             from .autograd import conv_train, epilogue_train
             feats = conv_train(x.F, x.map, out_map, self, self.kernel_size, self.transposed, out_channels)
+            if GATE_LOG is not None and act != ACT_NONE:
+                ch = feats.shape[1]
+                pre = feats.detach() if film is None else feats.detach() * film.detach()[:, :ch] + film.detach()[:, ch:]
+                GATE_LOG.append((self, out_map.coords, pre > 0))
             if film is not None or act != ACT_NONE or residual is not None:
                 feats = epilogue_train(feats, film, residual, act)          # one kernel forward, one backward
             return SparseTensor(feats, coordinate_map=out_map)

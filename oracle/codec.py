@@ -294,7 +294,8 @@ class Codec:
         y_hat = SparseTensor(y.C, y_hat_f[0].t().contiguous(), 8)
         x_hat, points, preds = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k, coords=coords, cfg=self.cfg_s)
         return {"prediction": x_hat, "points": points, "occ_predictions": preds,
-                "likelihoods": {"y": y_lik, "z": z_lik}, "k": k}
+                "likelihoods": {"y": y_lik, "z": z_lik}, "k": k,
+                "rows": {"y": y.C, "z": z.C}}          # the coordinates the likelihood columns belong to, in column order
 
 
 # ----------------------------------------------------------------------------------------

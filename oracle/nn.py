@@ -100,13 +100,50 @@ def conv_transpose_generative(x, W, bias=None, ksize=3):
     return SparseTensor(out_c, _apply_conv(x.F, W, bias, nbr, out_c.shape[0]), x.stride // 2)
 
 
+# Activation gates of the implementation under test, forced onto the oracle (tests/test_train_model.py).  A ReLU is
+# discontinuous in its gradient: a pre-activation within the two implementations' ~1e-7 difference of zero is gated open on
+# one side and closed on the other, and that one gate changes the gradients of its whole neighbourhood — a legitimate
+# difference that would otherwise have to be covered by a loose gradient tolerance.  With FORCED_GATES = {layer name:
+# (coordinates [n, 4], gate bool [n, C])} the activation of that layer multiplies by the GIVEN gate (rows matched by
+# coordinate; rows the other side did not evaluate keep their own gate), so both sides differentiate the same piecewise-
+# linear function and gradients can be held to the tight tolerance; every element whose own sign disagrees with the forced
+# gate is logged to GATE_FLIPS as (layer, |pre-activation|, largest |pre-activation| of the layer).
+FORCED_GATES = None
+GATE_FLIPS = None
+
+
+def _activate(x, neg_slope):
+    tag = getattr(x, "tag", None)
+    own = x.F > 0
+    gate = own
+    if FORCED_GATES is not None and tag in FORCED_GATES:
+        f_coords, f_gate = FORCED_GATES[tag]
+        idx = oc.lookup(oc.to_int_coords(f_coords), x.C)
+        hit = torch.from_numpy(idx >= 0)
+        gate = own.clone()
+        gate[hit] = torch.as_tensor(f_gate, dtype=torch.bool)[torch.from_numpy(idx[idx >= 0])]
+        if GATE_FLIPS is not None:
+            flipped = gate != own
+            if bool(flipped.any()):
+                top = float(x.F.detach().abs().max())
+                GATE_FLIPS.extend((tag, float(v), top) for v in x.F.detach()[flipped].abs().tolist())
+    out = x.F * gate if neg_slope == 0.0 else x.F * torch.where(gate, 1.0, neg_slope)
+    y = SparseTensor(x.C, out, x.stride)
+    y._cache = x._cache
+    return y
+
+
 def relu(x):
+    if FORCED_GATES is not None:
+        return _activate(x, 0.0)
     y = SparseTensor(x.C, torch.relu(x.F), x.stride)
     y._cache = x._cache
     return y
 
 
 def leaky_relu(x, slope=0.01):
+    if FORCED_GATES is not None:
+        return _activate(x, slope)
     y = SparseTensor(x.C, torch.nn.functional.leaky_relu(x.F, slope), x.stride)
     y._cache = x._cache
     return y
@@ -133,8 +170,12 @@ class Params:
 
     def conv(self, x, name, ksize=3, stride=1):
         p = self.sub(name)
-        return conv(x, p.get("kernel"), p.get("bias"), ksize, stride)
+        y = conv(x, p.get("kernel"), p.get("bias"), ksize, stride)
+        y.tag = self.prefix + name            # the layer's state_dict name: keys FORCED_GATES
+        return y
 
     def convT(self, x, name, ksize=3):
         p = self.sub(name)
-        return conv_transpose_generative(x, p.get("kernel"), p.get("bias"), ksize)
+        y = conv_transpose_generative(x, p.get("kernel"), p.get("bias"), ksize)
+        y.tag = self.prefix + name
+        return y

@@ -87,6 +87,45 @@ def test_stride_map(pcc, ts):
     assert (d.lookup(d.coords).cpu().numpy() == np.arange(got.shape[0])).all()
 
 
+@pytest.mark.parametrize("bad", [(0, 1 << 15, 5, 5), (0, 5, -(1 << 15), 5), (0, 7, 7, 32001), (32767, 1, 2, 3), (0, 65536 + 3, 4, 5)])
+def test_coordinates_outside_the_key_range_are_an_error_not_an_alias(pcc, model_for_range, bad):
+    """16 bits per key field (csrc/common.h): a 2^15 / 16-bit-voxelised coordinate would wrap onto another voxel's key.
+    The next coordinate-set construction reports it with the row count (PCC_COUNT_ERR_RANGE) and the Python side raises
+    ValueError — from the operator, from ColorModel.compress and from decompress; the limit itself is accepted."""
+    c = shell_coords(pcc, grid=24, radius=9.0)
+    ok = np.concatenate([c, np.array([[0, 32000, -32000, 32000], [32766, 0, 0, 0]], np.int32)])
+    assert pcc.CoordMap(dev(ok), 1).down().n > 0                                  # both limits are inside
+    assert pcc.CoordMap(dev(np.array([[0, 31992, -31992, 0], [1, 8, 8, 8]], np.int32)), 8).up(3).n == 54      # children at +-4: inside
+    cb = np.concatenate([c, np.array([bad], np.int32)])
+    with pytest.raises(ValueError, match="outside the supported range"):
+        pcc.CoordMap(dev(cb), 1).down()
+    if bad[0] == 0:
+        pts = np.concatenate([cb[:, 1:].astype(np.float32), np.full((cb.shape[0], 3), 0.5, np.float32)], axis=1)
+        qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+        Q = pcc.SparseTensor(coordinates=dev(qc), features=dev(qf), device=DEV)
+        with pytest.raises(ValueError, match="outside the supported range"):
+            model_for_range.compress(dev(pts), Q)
+        with pytest.raises(ValueError, match="outside the supported range"):
+            model_for_range.decompress(coordinates=dev(np.array([[0, 0, 0, 0], list(bad)], np.int32)), strings=[[b""], [b""]],
+                                       shape=[1], k=[[1], [1], [1]])
+
+
+def test_children_beyond_the_key_range_are_reported(pcc):
+    """a parent at the limit whose generated children step over it"""
+    c = np.array([[0, 31996, 0, 0], [0, 0, 0, 0]], np.int32)
+    assert pcc.CoordMap(dev(c), 4).up(2).n == 16                                  # children at +0 / +2: inside
+    c[0, 1] = 32000
+    with pytest.raises(ValueError, match="outside the supported range"):
+        pcc.CoordMap(dev(c), 8).up(3)                                             # a child at 32004
+
+
+@pytest.fixture(scope="module")
+def model_for_range(pcc):
+    m = pcc.synthetic.make_model(0, DEV)
+    m.update()
+    return m
+
+
 @pytest.mark.parametrize("ksize", [2, 3])
 def test_children(pcc, ksize):
     c = shell_coords(pcc, grid=24, radius=9.0) * np.array([1, 8, 8, 8], dtype=np.int32)

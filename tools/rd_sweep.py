@@ -2,7 +2,9 @@
 """RD sweep of BASELINE config 3: 4 synthetic frames with the point counts of
 redandblack / loot / longdress / soldier x the 4 (q_g, q_a) pairs of plot.py:31-32, each through
 file-mode compress / decompress + GPU metrics; Bjontegaard deltas between the frames' curves.
-Seeded random weights: the rates and PSNRs exercise the pipeline, they are not codec quality.
+Seeded random weights in their q-RESPONSIVE variant (synthetic.FILM_GAIN_Q_RESPONSIVE: FiLM heads with gain 1.0, so the rate
+follows the quality map; PCC_SWEEP_FILM_GAIN overrides): the rate axis is a real sweep, the distortion axis is that of random
+weights — not codec quality.
 
 usage: rd_sweep.py [out.json] [weights.pt]"""
 import json, os, sys, tempfile, time
@@ -17,7 +19,8 @@ from pcc_amd.metrics import Bjontegaard_Delta, Bjontegaard_Model
 dev = "cuda:0"
 FRAMES = {"redandblack~": 247.0, "loot~": 255.0, "longdress~": 261.5, "soldier~": 294.5}   # shell radii -> ~0.76 / 0.81 / 0.86 / 1.09 M
 QS = [(0.05, 0.1), (0.1, 0.2), (0.2, 0.4), (0.4, 0.8)]
-model = syn.make_model(seed=0, device=dev)
+film_gain = float(os.environ.get("PCC_SWEEP_FILM_GAIN", syn.FILM_GAIN_Q_RESPONSIVE))
+model = syn.make_model(seed=0, device=dev, film_gain=film_gain)
 if len(sys.argv) > 2:
     model.load_state_dict(torch.load(sys.argv[2], map_location=dev))
 model.update()
@@ -46,7 +49,9 @@ for nm in names[1:]:
         bd[nm] = {"error": repr(e)}
 out = {"rows": rows, "bjontegaard": bd,
        "note": ("weights from " + os.path.basename(sys.argv[2]) if len(sys.argv) > 2 else "seeded random weights") +
-               "; synthetic shells sized like the 8iVFB frames"}
+               f" (FiLM-head gain {film_gain}); synthetic shells sized like the 8iVFB frames",
+       "rate_axis_monotone_in_q": {nm: [r["bpp"] for r in rows if r["frame"] == nm] == sorted(r["bpp"] for r in rows if r["frame"] == nm)
+                                   for nm in names}}
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "rd_sweep.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
