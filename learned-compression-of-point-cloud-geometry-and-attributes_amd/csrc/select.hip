@@ -239,6 +239,11 @@ __global__ __launch_bounds__(256) void order_keys64_kernel(const uint32_t* __res
     keys[i] = key;
 }
 
+__global__ __launch_bounds__(256) void iota_kernel(int32_t* __restrict__ v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
 // Permuted neighbour table + one OR-mask per 32 positions.  A block owns 256 consecutive positions: their source
 // rows are staged in LDS, the masks of a 32-position group are OR-reduced inside its half-wave, and the table rows
 // (K ints each, contiguous in the source) are copied with the destination fully coalesced.
@@ -315,8 +320,18 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     uint32_t* bit_counts = reinterpret_cast<uint32_t*>(p + radix_sort_counter_bytes(n));       // 27 words in the scratch's 256-byte tail
     PCC_CHECK_HIP(hipMemsetAsync(bit_counts, 0, 27 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(mask_bit_counts_kernel, dim3(blocks_for(n, 256 * 16, 512)), dim3(256), 0, st, row_mask, n, bit_counts);
-    static int legacy = -1;      // PCC_ORDER_KEY=popcount: round 1's key (27 - popcount) << 27 | mask, for A/B runs
-    if (legacy < 0) { const char* e = getenv("PCC_ORDER_KEY"); legacy = (e && e[0] == 'p') ? 1 : 0; }
+    static int legacy = -1;      // PCC_ORDER_KEY=popcount: round 1's key (27 - popcount) << 27 | mask; =natural: rows stay in
+    if (legacy < 0) {            // the map's own (generation) order — experiments on gather locality, never the default
+        const char* e = getenv("PCC_ORDER_KEY");
+        legacy = (e && e[0] == 'p') ? 1 : (e && e[0] == 'n') ? 2 : 0;
+    }
+    if (legacy == 2) {
+        hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, n);
+        hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
+                           nbr_sorted, group_mask32);
+        PCC_LAUNCH_CHECK();
+        return PCC_OK;
+    }
     const int begin = 0, end = block_log2 >= 0 ? 64 : (legacy ? 32 : 27);
     // the sorted values must land in `order`: they end in the b-side when the pass count is odd
     const bool in_b = radix_sort_result_in_b(begin, end);

@@ -172,12 +172,25 @@ class GradBucketReducer:
     codec has structurally unused ones: gdn, conv_layers, q_up_i.conv_2) contribute zeros, so every
     rank issues the same collectives whatever its data.
 
+    Two collective schedules per bucket (``mode``), the same averaged gradients on every rank either way:
+    * ``"all_reduce"`` (default): one asynchronous all-reduce launched from the backward hooks;
+    * ``"reduce_scatter"``: an asynchronous reduce-scatter from the hooks (each rank ends up owning the sum of a 1/W
+      slice), and in ``finish()`` the scaling of the owned slice followed by an all-gather.  On the point-to-point
+      xGMI mesh of an 8 x MI355X node this is the schedule SURVEY.md §5 argues for: the reduce-scatter half hides
+      under backward like the all-reduce did, the all-gather half moves (W-1)/W of a bucket once, and a sharded
+      optimizer could later step between the two halves.  Which one is faster on the node is a measurement the 8-GPU
+      box has to make (tools/train_bench.py --reducer); both are covered by world-2 gloo tests and run over RCCL with
+      a world of one rank.
+
     usage:  red = GradBucketReducer(model.parameters());  loss.backward();  red.finish();  opt.step()
     """
 
-    def __init__(self, params, bucket_bytes=32 << 20, group=None, always_reduce=False):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, always_reduce=False, mode="all_reduce"):
         """always_reduce: issue the collectives even in a world of one rank (a process group must be up) — how a one-GPU
         box exercises the RCCL calls of the N-GPU path; the result is unchanged (sum over one rank, divided by one)"""
+        if mode not in ("all_reduce", "reduce_scatter"):
+            raise ValueError(f"GradBucketReducer: unknown mode {mode!r}")
+        self.mode = mode
         self.group = group
         up = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if up else 1
@@ -204,7 +217,11 @@ class GradBucketReducer:
         self._arm()
 
     def _close(self, plist, elems):
-        flat = torch.zeros(elems, dtype=torch.float32, device=plist[0].device)
+        if self.mode == "reduce_scatter":
+            elems_p = (elems + self.world - 1) // self.world * self.world          # equal slices: zero padding at the tail
+        else:
+            elems_p = elems
+        flat = torch.zeros(elems_p, dtype=torch.float32, device=plist[0].device)
         items, off = [], 0
         for p in plist:
             items.append((p, off, p.numel()))
@@ -224,7 +241,12 @@ class GradBucketReducer:
                 flat[off:off + n].zero_()
             else:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
-        if self.collective:
+        if self.collective and self.mode == "reduce_scatter":
+            n_shard = flat.numel() // self.world
+            shard = flat.new_empty(n_shard)
+            work = dist.reduce_scatter_tensor(shard, flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works[b] = (work, shard)
+        elif self.collective:
             self._works[b] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
@@ -241,10 +263,17 @@ class GradBucketReducer:
         for b, (flat, items) in enumerate(self.buckets):
             if self._pending[b] > 0:          # holds parameters without a gradient this step
                 self._launch(b)
-            if self._works[b] is not None:
-                self._works[b].wait()
-            if self.world > 1:
-                flat.div_(self.world)
+            if isinstance(self._works[b], tuple):                  # reduce-scatter done: scale my slice, gather all slices
+                work, shard = self._works[b]
+                work.wait()
+                if self.world > 1:
+                    shard.div_(self.world)
+                dist.all_gather_into_tensor(flat, shard, group=self.group)
+            else:
+                if self._works[b] is not None:
+                    self._works[b].wait()
+                if self.world > 1:
+                    flat.div_(self.world)
             for p, off, n in items:
                 if p.grad is not None:
                     p.grad.copy_(flat[off:off + n].view_as(p.grad))
