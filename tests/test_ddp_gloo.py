@@ -33,15 +33,17 @@ class Net(torch.nn.Module):
         return self.c(torch.relu(self.b(h)) + h)     # h is used twice: one accumulation per parameter all the same
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="all_reduce"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pcc_amd.parallel import GradBucketReducer
     torch.manual_seed(0)
     net = Net()                                       # same initial weights on every rank
-    red = GradBucketReducer(net.parameters(), bucket_bytes=64 * 1024)      # several buckets
+    red = GradBucketReducer(net.parameters(), bucket_bytes=64 * 1024, mode=mode)      # several buckets
     assert len(red.buckets) >= 3
+    if mode == "reduce_scatter":                      # equal slices per rank; at least one bucket needed tail padding
+        assert all(flat.numel() % world == 0 for flat, _ in red.buckets)
     ok = True
     for step in range(3):
         g = torch.Generator().manual_seed(1000 * step + rank)
@@ -64,11 +66,21 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_bucketed_gradient_average_world2(tmp_path):
-    world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+@pytest.mark.parametrize("mode,world", [("all_reduce", 2), ("reduce_scatter", 2), ("reduce_scatter", 3)])
+def test_bucketed_gradient_average(tmp_path, mode, world):
+    """both collective schedules (one all-reduce per bucket; reduce-scatter from the hooks + all-gather in finish()) hand
+    every rank the mean gradient; world 3 makes the reduce-scatter slices need tail padding (bucket sizes not divisible)"""
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path), mode), nprocs=world, join=True)
     for r in range(world):
         assert open(os.path.join(str(tmp_path), f"ok{r}")).read() == "1"
+
+
+def test_reducer_rejects_an_unknown_mode():
+    sys.path.insert(0, ROOT)
+    from pcc_amd.parallel import GradBucketReducer
+    with pytest.raises(ValueError):
+        GradBucketReducer(Net().parameters(), mode="ring")
 
 
 def _aux_worker(rank, world, port, out_dir):

@@ -59,14 +59,17 @@ def test_bench_multi_gpu_branches_over_rccl_world_of_one(partition):
         assert line["blocks"]["decoded_points"] == line["blocks"]["points_per_frame"]
 
 
-def test_training_step_reducer_over_rccl_world_of_one():
+@pytest.mark.parametrize("reducer", ["all_reduce", "reduce_scatter"])
+def test_training_step_reducer_over_rccl_world_of_one(reducer):
     """tools/train_bench.py with the process group up: GradBucketReducer's post-accumulate hooks launch their bucketed
-    all-reduces on RCCL during backward, red.finish() waits for them, Adam steps; the loss stays finite"""
-    r = _run([sys.executable, "tools/train_bench.py", "--batch", "2", "--block", "128", "--steps", "2", "--warmup", "1"],
-             {"PCC_BENCH_FORCE_DIST": "1"}, timeout=400)
+    collectives (all-reduce, or reduce-scatter followed by the all-gather of finish()) on RCCL during backward,
+    red.finish() waits for them, Adam steps; the loss stays finite"""
+    r = _run([sys.executable, "tools/train_bench.py", "--batch", "2", "--block", "128", "--steps", "2", "--warmup", "1",
+              "--reducer", reducer], {"PCC_BENCH_FORCE_DIST": "1"}, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["last_loss"] == line["last_loss"]      # not NaN
+    assert line["reducer"] == reducer
 
 
 def test_bench_starts_its_own_two_ranks():

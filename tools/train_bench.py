@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--block", type=int, default=128)
+    ap.add_argument("--reducer", default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                    help="collective schedule of the gradient buckets (parallel.GradBucketReducer): one all-reduce per bucket, or "
+                         "reduce-scatter under backward + all-gather before the optimizer step")
     args = ap.parse_args()
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", 1))
@@ -63,7 +66,7 @@ def main():
     rng = random.Random(1234 + rank)
     params = [p for n, p in model.named_parameters() if not n.endswith(".quantiles")]      # train.py:63-64
     opt = torch.optim.Adam(params, lr=1e-4)
-    red = par.GradBucketReducer(params, always_reduce=active)
+    red = par.GradBucketReducer(params, always_reduce=active, mode=args.reducer)
     qgen = Q_Map({"mode": "exponential", "lambda_A_max": 12800, "lambda_A_min": 100, "lambda_G_max": 1600, "lambda_G_min": 25})
     loss_fn = Loss(OURS_LOSS)
     random.seed(99 + rank)
@@ -116,7 +119,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "training points/sec", "value": npts / el, "unit": "points/s", "n_gpus": world, "steps": args.steps,
                           "ms_per_step": el / args.steps * 1e3, "batch_cubes_per_gpu": args.batch, "block": args.block,
-                          "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic", "rccl": rccl}))
+                          "points_per_step": npts / args.steps, "dtype": ("bf16 operands on the wide convolutions, fp32 accumulation" if os.environ.get("PCC_TRAIN_BF16") == "1" else "f32"), "last_loss": last, "data": "synthetic", "reducer": args.reducer, "rccl": rccl}))
     feed.close()
     if active:
         dist.destroy_process_group()
