@@ -158,6 +158,24 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
                  const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
                  int32_t act, const float* film, const float* residual, void* stream);
 
+/* Convolution in the map's own row order with compacted offset lists (csrc/conv_co.hip) — the default of the fp32
+ * inference path for kernel maps (cin % 32 == 0, cout % 64 == 0).  pcc_compact_map turns a kernel map nbr [n_out, K] into,
+ * per group of PCC_COMPACT_GROUP consecutive output rows and per offset k, the list of the group's rows that have a
+ * neighbour at k: ent_in [groups, K, PCC_COMPACT_GROUP] int32 (input row of list entry p, -1 = padding), ent_row4
+ * [groups, K, 32] uint32 (byte s of word r = group-local output row of entry 32 s + r; padding names row
+ * PCC_COMPACT_GROUP) and cnt [groups, 32] uint8 (list lengths); groups = pcc_compact_map_groups(n_out).  Built once per
+ * map, shared by every convolution on it.  pcc_conv_fwd_co computes the same out = act(film(bias + sum_k in[nbr] @ W[k]))
+ * + residual as pcc_conv_fwd, bit for bit (same per-element MFMA chain: offsets ascending, channels ascending), with every
+ * MFMA tile holding 32 list entries — full whatever the rows' neighbour masks are — and gathers that stay local.
+ * w_packed from pcc_conv_pack_weights; fin, w_packed, fout, bias, film, residual 16-byte aligned; operands < 4 GiB. */
+#define PCC_COMPACT_GROUP 128
+int64_t pcc_compact_map_groups(int64_t n_out);
+int pcc_compact_map(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* ent_in, uint32_t* ent_row4, uint8_t* cnt,
+                    void* stream);
+int pcc_conv_fwd_co(const float* fin, int64_t n_in, int32_t cin, const float* w_packed, const float* bias,
+                    const int32_t* ent_in, const uint32_t* ent_row4, const uint8_t* cnt, int32_t K, float* fout,
+                    int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
+
 /* bf16-input variant of pcc_conv_fwd (training / BASELINE config 5): features and packed weights are bf16
  * (fin [n_in, cin] bf16, cin a multiple of 64; pcc_conv_pack_weights_bf16: [K, cin/8, cout^32, 8]), products
  * accumulate in fp32 on v_mfma_f32_32x32x16_bf16, bias / FiLM / activation / residual and the output are fp32.

@@ -36,6 +36,10 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_conv_fwd": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                              c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_compact_map_groups": (c_i64, [c_i64]),
+    "pcc_compact_map": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pcc_conv_fwd_co": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i64,
+                                c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_conv_packed_elems_bf16": (c_i64, [c_i32, c_i32, c_i32]),
     "pcc_conv_pack_weights_bf16": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "pcc_conv_fwd_bf16": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i64,

@@ -103,8 +103,8 @@ def prefetch_up_maps(x_map):
     side.wait_stream(main)
     with torch.cuda.stream(side):
         cand = x_map.up(3)
-        x_map.ordered_kernel_map(cand, 3, True)
-        cand.ordered_kernel_map(cand, 3)
+        x_map.mfma_kernel_map(cand, 3, True)
+        cand.mfma_kernel_map(cand, 3)
         cand.kernel_map(cand, 3)
         x_map._cache[("prefetch_event",)] = side.record_event()
     x_map._cache[key] = True

@@ -124,12 +124,12 @@ class MeanScaleHyperprior_Map(nn.Module):
         # the z stream needs nothing from the GPU: its host decode runs while the GPU builds what depends on coordinates
         # only — the tables and kernel maps of h_s (z -> 16 -> 8, evaluated at y) and of the first h_q layer
         finish_z = self.entropy_bottleneck.decompress_features_async(z_strings, int(shape[0]), z_sorted.device)
-        z_sorted.ordered_kernel_map(z_sorted, 3)
+        z_sorted.mfma_kernel_map(z_sorted, 3)
         z16 = z_sorted.up(2)
-        z_sorted.ordered_kernel_map(z16, 2, True)
-        z16.ordered_kernel_map(z16, 3)
-        z16.ordered_kernel_map(z16.up(2), 2, True)
-        z16.up(2).ordered_kernel_map(y_sorted, 3)
+        z_sorted.mfma_kernel_map(z16, 2, True)
+        z16.mfma_kernel_map(z16, 3)
+        z16.mfma_kernel_map(z16.up(2), 2, True)
+        z16.up(2).mfma_kernel_map(y_sorted, 3)
         z_hat = SparseTensor(finish_z(), coordinate_map=z_sorted)
         # h_s first: its output (scales | means) is what the serial rANS decode of y is waiting for.  While
         # the host decodes (~15 ms for 2.5 M symbols) the GPU runs everything that does not need y: h_q
@@ -144,11 +144,11 @@ class MeanScaleHyperprior_Map(nn.Module):
     @staticmethod
     def _prefetch_synthesis_maps(y_map, q_map):
         """Fill the kernel-map caches g_s will hit first (pure functions of the coordinates)."""
-        y_map.ordered_kernel_map(y_map, 3)                    # cond_conv, pre_conv, scale_1 on the y set
-        q_map.ordered_kernel_map(q_map, 3)                    # q_predict_1 on the dilated q-map support
+        y_map.mfma_kernel_map(y_map, 3)                    # cond_conv, pre_conv, scale_1 on the y set
+        q_map.mfma_kernel_map(q_map, 3)                    # q_predict_1 on the dilated q-map support
         q_map.kernel_map(q_map, 3)                            # q_pre_conv (thin convolutions)
-        q_map.ordered_kernel_map(y_map, 3)                    # q_predict_1's last conv evaluated at y
+        q_map.mfma_kernel_map(y_map, 3)                    # q_predict_1's last conv evaluated at y
         cand = y_map.up(3)                                    # up_1 candidates
-        y_map.ordered_kernel_map(cand, 3, True)
-        cand.ordered_kernel_map(cand, 3)
+        y_map.mfma_kernel_map(cand, 3, True)
+        cand.mfma_kernel_map(cand, 3)
         cand.kernel_map(cand, 3)

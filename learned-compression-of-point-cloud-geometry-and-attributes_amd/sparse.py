@@ -227,6 +227,32 @@ class CoordMap:
         self._cache[key] = (None if out_map is self else out_map, nbr_sorted, order, gmask, pairs)
         return nbr_sorted, order, gmask, pairs
 
+    def compact_kernel_map(self, out_map, ksize, transposed=False):
+        """Kernel map as per-group compacted offset lists (csrc/conv_co.hip): (ent_in int32 [G, K, 128], ent_row4 int32
+        [G, K, 32], cnt uint8 [G, 32], pair_count) for groups of 128 consecutive output rows — the form the fp32 inference
+        convolutions run on: rows stay in the map's own order, every MFMA tile holds 32 list entries."""
+        key = ("cmap", id(out_map), ksize, transposed)
+        hit = self._cache.get(key)
+        if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
+            return hit[1:]
+        nbr, _, pairs = self.kernel_map(out_map, ksize, transposed)
+        L = _lib.lib()
+        n_out, K = nbr.shape
+        dev = self.device
+        groups = L.pcc_compact_map_groups(n_out)
+        ent_in = torch.empty((groups, K, COMPACT_GROUP), dtype=torch.int32, device=dev)
+        ent_row4 = torch.empty((groups, K, 32), dtype=torch.int32, device=dev)
+        cnt = torch.empty((groups, 32), dtype=torch.uint8, device=dev)
+        check(L.pcc_compact_map(ptr(nbr), n_out, K, ptr(ent_in), ptr(ent_row4), ptr(cnt), _lib.stream()))
+        self._cache[key] = (None if out_map is self else out_map, ent_in, ent_row4, cnt, pairs)
+        return ent_in, ent_row4, cnt, pairs
+
+    def mfma_kernel_map(self, out_map, ksize, transposed=False):
+        """Build (and cache) the map form the wide inference convolutions will ask for — what the prefetchers call"""
+        if CONV_CO:
+            return self.compact_kernel_map(out_map, ksize, transposed)
+        return self.ordered_kernel_map(out_map, ksize, transposed)
+
     def count_per_batch(self):
         """AnalysisTransform.count_per_batch (model/transforms.py:65-71)."""
         if self._nbatch == 1:
@@ -439,6 +465,10 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     if ksize > 1 and cin % 32 == 0 and cout <= NARROW_HEAD_MAX_COUT and film is None and residual is None:
         return _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels)
     order = gmask = None
+    bf16 = INFER_BF16 and cin % 64 == 0 and x_feats.shape[0] * cin * 2 < 0xFFFFF000
+    if (CONV_CO and ksize > 1 and cin % 32 == 0 and cin <= 256 and cout % 64 == 0 and not bf16 and not INFER_X3
+            and x_feats.shape[0] * cin * 4 < 0xFFFFF000 and out_map.n * ksize ** 3 * 4 < 0xFFFFE000):
+        return _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual)
     if ksize == 1:
         nbr = pairs = None
         K = 1
@@ -450,7 +480,6 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         K = ksize ** 3
     n_out = out_map.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
-    bf16 = INFER_BF16 and cin % 64 == 0 and x_feats.shape[0] * cin * 2 < 0xFFFFF000
     x3 = (INFER_X3 and not bf16 and cin % 32 == 0 and ((cout + 31) // 32 * 32) % 64 == 0 and x_feats.shape[0] * cin * 4 < 0xFFFFF000
           and (nbr is None or n_out * K * 4 < 0xFFFFF000))
     prof = PROFILER
@@ -477,6 +506,25 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     return out
 
 
+def _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual):
+    """the wide fp32 convolution on compacted offset lists (csrc/conv_co.hip): same result as pcc_conv_fwd, bit for bit"""
+    L = _lib.lib()
+    ent_in, ent_row4, cnt, pairs = in_map.compact_kernel_map(out_map, ksize, transposed)
+    cin, cout, n_out, K = x_feats.shape[1], w.shape[-1], out_map.n, ksize ** 3
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
+    prof = PROFILER
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.pcc_conv_fwd_co(ptr(x_feats), x_feats.shape[0], cin, ptr(wp), ptr(bias), ptr(ent_in), ptr(ent_row4), ptr(cnt), K,
+                            ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+    if prof is not None:
+        ev1.record()
+        prof.append((f"conv_co_kernel<{128 if cout % 128 == 0 else 64}, {cin // 32}>", cin, cout, pairs, n_out, ev0, ev1, cnt))
+    return out
+
+
 def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels):
     """cout <= 4 on wide inputs (occupancy logit, q-map heads): per-input-row scores by one dense MFMA
     GEMM, then a scalar gather-sum per output row (see csrc/conv.hip, gather_sum_kernel)."""
@@ -500,6 +548,17 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
         ev1.record()
         prof.append((f"narrow_head<{cin}>", cin, cout, pairs, n_out, ev0, ev1, None))
     return out
+
+
+# The wide fp32 inference convolutions run on compacted offset lists in the map's own row order (csrc/conv_co.hip);
+# PCC_CONV_CO=0 takes the mask-ordered kernel of csrc/conv.hip instead (A/B runs; results are bit-identical).
+CONV_CO = os.environ.get("PCC_CONV_CO", "1") == "1"
+COMPACT_GROUP = 128        # PCC_COMPACT_GROUP of include/pcc_hip.h
+
+
+def set_conv_co(enabled):
+    global CONV_CO
+    CONV_CO = bool(enabled)
 
 
 # Output widths up to this use the narrow-head path (K * cout score columns must fit one 128-wide GEMM tile).
