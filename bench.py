@@ -537,6 +537,9 @@ def main():
         if gmask is None:
             return (n_out + 31) // 32
         key = gmask.data_ptr()
+        if key not in pop_cache and gmask.dtype == torch.int16:
+            # compacted-offset kernel: list lengths per (group, offset); a list executes ceil(length / 32) tiles
+            pop_cache[key] = int(((gmask.cpu().numpy().astype(np.int64) + 31) // 32).sum())
         if key not in pop_cache:
             # counted on the host: 27 tiny device reductions per map would fill the kernel trace
             pop_cache[key] = int(np.unpackbits(gmask.cpu().numpy().view(np.uint8)).sum())

@@ -162,13 +162,14 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
  * inference path for kernel maps (cin % 32 == 0, cout % 64 == 0).  pcc_compact_map turns a kernel map nbr [n_out, K] into,
  * per group of PCC_COMPACT_GROUP consecutive output rows and per offset k, the list of the group's rows that have a
  * neighbour at k: ent_in [groups, K, PCC_COMPACT_GROUP] int32 (input row of list entry p, -1 = padding), ent_row4
- * [groups, K, 32] uint32 (byte s of word r = group-local output row of entry 32 s + r; padding names row
- * PCC_COMPACT_GROUP) and cnt [groups, 32] uint8 (list lengths); groups = pcc_compact_map_groups(n_out).  Built once per
+ * [groups, K, 2, 32] uint32 (byte i of word (sp, r) = group-local output row of entry 32 (sp + 2 i) + r; a padding
+ * entry names a row of the group that is not in the list) and cnt [groups, 32] uint16 passed as bytes [groups, 64]
+ * (list lengths 0 .. 256); groups = pcc_compact_map_groups(n_out).  Built once per
  * map, shared by every convolution on it.  pcc_conv_fwd_co computes the same out = act(film(bias + sum_k in[nbr] @ W[k]))
  * + residual as pcc_conv_fwd, bit for bit (same per-element MFMA chain: offsets ascending, channels ascending), with every
  * MFMA tile holding 32 list entries — full whatever the rows' neighbour masks are — and gathers that stay local.
  * w_packed from pcc_conv_pack_weights; fin, w_packed, fout, bias, film, residual 16-byte aligned; operands < 4 GiB. */
-#define PCC_COMPACT_GROUP 128
+#define PCC_COMPACT_GROUP 256
 int64_t pcc_compact_map_groups(int64_t n_out);
 int pcc_compact_map(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* ent_in, uint32_t* ent_row4, uint8_t* cnt,
                     void* stream);

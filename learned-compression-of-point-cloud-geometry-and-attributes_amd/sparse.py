@@ -228,8 +228,8 @@ class CoordMap:
         return nbr_sorted, order, gmask, pairs
 
     def compact_kernel_map(self, out_map, ksize, transposed=False):
-        """Kernel map as per-group compacted offset lists (csrc/conv_co.hip): (ent_in int32 [G, K, 128], ent_row4 int32
-        [G, K, 32], cnt uint8 [G, 32], pair_count) for groups of 128 consecutive output rows — the form the fp32 inference
+        """Kernel map as per-group compacted offset lists (csrc/conv_co.hip): (ent_in int32 [G, K, 256], ent_row4 int32
+        [G, K, 2, 32], cnt int16 [G, 32], pair_count) for groups of 256 consecutive output rows — the form the fp32 inference
         convolutions run on: rows stay in the map's own order, every MFMA tile holds 32 list entries."""
         key = ("cmap", id(out_map), ksize, transposed)
         hit = self._cache.get(key)
@@ -241,8 +241,8 @@ class CoordMap:
         dev = self.device
         groups = L.pcc_compact_map_groups(n_out)
         ent_in = torch.empty((groups, K, COMPACT_GROUP), dtype=torch.int32, device=dev)
-        ent_row4 = torch.empty((groups, K, 32), dtype=torch.int32, device=dev)
-        cnt = torch.empty((groups, 32), dtype=torch.uint8, device=dev)
+        ent_row4 = torch.empty((groups, K, 2, 32), dtype=torch.int32, device=dev)
+        cnt = torch.empty((groups, 32), dtype=torch.int16, device=dev)
         check(L.pcc_compact_map(ptr(nbr), n_out, K, ptr(ent_in), ptr(ent_row4), ptr(cnt), _lib.stream()))
         self._cache[key] = (None if out_map is self else out_map, ent_in, ent_row4, cnt, pairs)
         return ent_in, ent_row4, cnt, pairs
@@ -521,7 +521,7 @@ def _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, a
                             ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     if prof is not None:
         ev1.record()
-        prof.append((f"conv_co_kernel<{128 if cout % 128 == 0 else 64}, {cin // 32}>", cin, cout, pairs, n_out, ev0, ev1, cnt))
+        prof.append((f"conv_co_kernel<{cin // 32}>", cin, cout, pairs, n_out, ev0, ev1, cnt))
     return out
 
 
@@ -553,7 +553,7 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
 # The wide fp32 inference convolutions run on compacted offset lists in the map's own row order (csrc/conv_co.hip);
 # PCC_CONV_CO=0 takes the mask-ordered kernel of csrc/conv.hip instead (A/B runs; results are bit-identical).
 CONV_CO = os.environ.get("PCC_CONV_CO", "1") == "1"
-COMPACT_GROUP = 128        # PCC_COMPACT_GROUP of include/pcc_hip.h
+COMPACT_GROUP = 256        # PCC_COMPACT_GROUP of include/pcc_hip.h
 
 
 def set_conv_co(enabled):

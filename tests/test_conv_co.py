@@ -3,7 +3,7 @@ kernel of csrc/conv.hip — BIT FOR BIT, the property that lets the two be swapp
 (oracle/nn.py: per-offset gather -> sgemm -> index_add_) within the fp32 summation-order tolerance of the other convolution
 tests.  Shapes: every (cin, cout) class of configs/Ours.yaml that takes the path, same-map / strided / transposed (K = 27
 and K = 8) maps, dense shells and sparse random subsets (the sets an untrained decoder keeps), row counts that are not a
-multiple of the 128-row group, and one- and five-row sets."""
+multiple of the 256-row group, and one- and five-row sets."""
 import numpy as np
 import pytest
 import torch
@@ -40,23 +40,29 @@ def _coords(pcc, kind, seed=0):
     return c[rng.permutation(c.shape[0])]
 
 
-def _compact_reference(nbr, R=128):
-    """numpy restatement of pcc_compact_map"""
+def _compact_reference(nbr, R=256):
+    """numpy restatement of pcc_compact_map: lists per group of R rows and offset; padding entries gather nothing (-1) and
+    name the group's first row that is NOT in the list"""
     n, K = nbr.shape
     G = (n + R - 1) // R
     ent_in = np.full((G, K, R), -1, np.int32)
-    rows = np.full((G, K, R), R, np.int64)
-    cnt = np.zeros((G, 32), np.uint8)
+    rows = np.zeros((G, K, R), np.int64)
+    cnt = np.zeros((G, 32), np.int16)
     for g in range(G):
-        blk = nbr[g * R:(g + 1) * R]
+        blk = np.full((R, K), -1, np.int64)
+        blk[:min(R, n - g * R)] = nbr[g * R:(g + 1) * R]
         for k in range(K):
             r = np.nonzero(blk[:, k] >= 0)[0]
             ent_in[g, k, :r.size] = blk[r, k]
             rows[g, k, :r.size] = r
+            if r.size < R:
+                rows[g, k, r.size:] = np.nonzero(blk[:, k] < 0)[0][0]
             cnt[g, k] = r.size
-    row4 = np.zeros((G, K, 32), np.int64)
-    for s in range(R // 32):
-        row4 |= rows[:, :, 32 * s:32 * s + 32] << (8 * s)
+    row4 = np.zeros((G, K, 2, 32), np.int64)
+    for sp in range(2):
+        for i in range(R // 64):
+            s0 = 32 * (sp + 2 * i)
+            row4[:, :, sp, :] |= rows[:, :, s0:s0 + 32] << (8 * i)
     return ent_in, row4.astype(np.uint32).view(np.int32), cnt
 
 
@@ -138,7 +144,7 @@ def test_co_strided_and_transposed_maps(pcc, kind, geometry):
 
 
 def test_co_is_row_order_and_batch_composition_invariant_bitwise(pcc):
-    """a row's result depends on its own neighbourhood only: not on where the row sits, which group of 128 it falls into,
+    """a row's result depends on its own neighbourhood only: not on where the row sits, which group of 256 it falls into,
     or what else is in the launch (the property the decoder's reproduction of h_s rests on)"""
     torch.manual_seed(11)
     c = _coords(pcc, "shell")

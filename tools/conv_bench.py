@@ -53,9 +53,9 @@ for cin, cout in shapes:
             # the same table through the compacted-offset kernel (csrc/conv_co.hip): all 27 offsets present, so both kernels
             # issue the same MFMAs — what differs is accumulators through LDS, one workgroup per CU, the list indirection
             groups = L.pcc_compact_map_groups(n)
-            ent_in = torch.empty((groups, K, 128), dtype=torch.int32, device=dev)
-            ent_row4 = torch.empty((groups, K, 32), dtype=torch.int32, device=dev)
-            cnt = torch.empty((groups, 32), dtype=torch.uint8, device=dev)
+            ent_in = torch.empty((groups, K, 256), dtype=torch.int32, device=dev)
+            ent_row4 = torch.empty((groups, K, 2, 32), dtype=torch.int32, device=dev)
+            cnt = torch.empty((groups, 32), dtype=torch.int16, device=dev)
             check(L.pcc_compact_map(ptr(nbr), n, K, ptr(ent_in), ptr(ent_row4), ptr(cnt), _lib.stream()))
             out2 = torch.empty(n, cout, device=dev)
             for it in range(3):
