@@ -235,15 +235,17 @@ __global__ __launch_bounds__(256) void conv_co_kernel(const ConvCoArgs a) {
         // The DMAs of one step as numbered pieces, so that compute() can issue them one at a time between its MFMAs: this
         // workgroup is alone on its CU (one wave per SIMD), so an instruction that is not issued in the shadow of a running
         // MFMA idles the matrix pipe (an LDS-DMA costs ~60 issue cycles; ten of them in front of a step were 15 % of it).
-        // Pieces 0 .. RPT-1: my gather instructions (skipped past the list's end, wave-uniform); RPT .. RPT+W_LOADS-1: my
-        // share of the weight slab.
+        // Pieces 0 .. RPT-1: my gather instructions (skipped past the list's last tile, wave-uniform); RPT .. RPT+W_LOADS-1:
+        // my share of the weight slab.
         constexpr int NDMA = RPT + W_LOADS;
         auto dma_piece = [&](int k, int len, auto cc, auto bufc, auto pc) {
             constexpr int c = decltype(cc)::value;
             constexpr int buf = decltype(bufc)::value;
             constexpr int piece = decltype(pc)::value;
             if constexpr (piece < RPT) {
-                if ((piece * 4 + wave_u) * 8 < len)
+                // up to the end of the list's last TILE: its padding entries must read zeros (out-of-range lanes of an LDS-DMA
+                // write zeros), not what an earlier step left in the image — they add into a real row's accumulator
+                if ((piece * 4 + wave_u) * 8 < ((len + 31) & ~31))
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(As + buf * A_ELEMS + (piece * 4 + wave_u) * 256), 16,
                                                              a_voff[piece], c * 128, 0, 0);
             } else {

@@ -550,9 +550,12 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
     return out
 
 
-# The wide fp32 inference convolutions run on compacted offset lists in the map's own row order (csrc/conv_co.hip);
-# PCC_CONV_CO=0 takes the mask-ordered kernel of csrc/conv.hip instead (A/B runs; results are bit-identical).
-CONV_CO = os.environ.get("PCC_CONV_CO", "1") == "1"
+# Experimental, off by default: PCC_CONV_CO=1 / set_conv_co(True) runs the wide fp32 inference convolutions on compacted
+# offset lists in the map's own row order (csrc/conv_co.hip) instead of the mask-ordered kernel of csrc/conv.hip.  Results
+# are bit-identical (tests/test_conv_co.py); on the config-2 frame the mask-ordered kernel is the faster one on every layer
+# class (round 3, DESIGN.md §4: 73 ms of convolutions per frame against 104 ms) — one workgroup per CU and the accumulator
+# round trip through LDS at every kernel offset cost more than full tiles and local gathers return.
+CONV_CO = os.environ.get("PCC_CONV_CO", "0") == "1"
 COMPACT_GROUP = 256        # PCC_COMPACT_GROUP of include/pcc_hip.h
 
 

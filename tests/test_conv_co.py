@@ -80,14 +80,16 @@ def test_compact_map_lists(pcc, kind):
 
 
 def _both(pcc, layer, x, **kw):
+    """(compacted-offset kernel, mask-ordered kernel) on the same input"""
     from pcc_amd import sparse as sp
-    assert sp.CONV_CO
-    a = layer(x, **kw)
-    sp.set_conv_co(False)
+    was = sp.CONV_CO
     try:
+        sp.set_conv_co(True)
+        a = layer(x, **kw)
+        sp.set_conv_co(False)
         b = layer(x, **kw)
     finally:
-        sp.set_conv_co(True)
+        sp.set_conv_co(was)
     return a, b
 
 
@@ -150,17 +152,48 @@ def test_co_is_row_order_and_batch_composition_invariant_bitwise(pcc):
     c = _coords(pcc, "shell")
     n = c.shape[0]
     F = torch.randn(n, 128)
+    from pcc_amd import sparse as sp
     layer = pcc.MinkowskiConvolution(128, 128, kernel_size=3, stride=1, bias=True, dimension=3).to(DEV)
-    a = layer(pcc.SparseTensor(dev(F), coordinate_map=pcc.CoordMap(dev(c), 1))).F.cpu()
-    perm = np.random.default_rng(5).permutation(n)
-    b = layer(pcc.SparseTensor(dev(F[torch.from_numpy(perm)]), coordinate_map=pcc.CoordMap(dev(c[perm]), 1))).F.cpu()
-    assert torch.equal(a[torch.from_numpy(perm)], b)
-    # the same cloud as batch item 1 behind another cloud as item 0: different groups, same rows
-    c2 = _coords(pcc, "sparse", seed=4)
-    cc = np.concatenate([c2, c + np.array([1, 0, 0, 0], np.int32)])
-    FF = torch.cat([torch.randn(c2.shape[0], 128), F])
-    d = layer(pcc.SparseTensor(dev(FF), coordinate_map=pcc.CoordMap(dev(cc), 1))).F.cpu()
-    assert torch.equal(d[c2.shape[0]:], a)
+    was = sp.CONV_CO
+    sp.set_conv_co(True)
+    try:
+        a = layer(pcc.SparseTensor(dev(F), coordinate_map=pcc.CoordMap(dev(c), 1))).F.cpu()
+        perm = np.random.default_rng(5).permutation(n)
+        b = layer(pcc.SparseTensor(dev(F[torch.from_numpy(perm)]), coordinate_map=pcc.CoordMap(dev(c[perm]), 1))).F.cpu()
+        assert torch.equal(a[torch.from_numpy(perm)], b)
+        # the same cloud as batch item 1 behind another cloud as item 0: different groups, same rows
+        c2 = _coords(pcc, "sparse", seed=4)
+        cc = np.concatenate([c2, c + np.array([1, 0, 0, 0], np.int32)])
+        FF = torch.cat([torch.randn(c2.shape[0], 128), F])
+        d = layer(pcc.SparseTensor(dev(FF), coordinate_map=pcc.CoordMap(dev(cc), 1))).F.cpu()
+        assert torch.equal(d[c2.shape[0]:], a)
+    finally:
+        sp.set_conv_co(was)
+
+
+def test_co_codes_a_frame_to_the_same_bytes(pcc):
+    """the whole codec with the experimental kernel switched on: same streams, same reconstruction as the default kernels"""
+    from pcc_amd import sparse as sp
+    syn = pcc.synthetic
+    model = syn.make_model(0, DEV)
+    model.update()
+    pts = syn.sphere_shell(grid=96, radius=40.0, half_width=0.5)
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+
+    def run():
+        Q = pcc.SparseTensor(coordinates=dev(qc), features=dev(qf), device=DEV)
+        strings, shape, k, coords = model.compress(dev(pts), Q)
+        return strings, shape, k, model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+
+    was = sp.CONV_CO
+    try:
+        sp.set_conv_co(False)
+        s0, sh0, k0, r0 = run()
+        sp.set_conv_co(True)
+        s1, sh1, k1, r1 = run()
+    finally:
+        sp.set_conv_co(was)
+    assert s0 == s1 and sh0 == sh1 and k0 == k1 and torch.equal(r0, r1)
 
 
 def test_co_rejects_what_it_cannot_take(pcc):
