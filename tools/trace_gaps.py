@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--skip-steps", type=int, default=2, help="steps (marker triplets) to drop at the front: warm-up")
     ap.add_argument("--top", type=int, default=12)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--list", default=None, help="write the launch sequence of the last timed step here: phase, start (us from the "
+                                                 "phase's start), gap before (us), duration (us), kernel")
     args = ap.parse_args()
     rows = []
     with open(args.trace) as f:
@@ -57,6 +59,17 @@ def main():
     steps = steps[args.skip_steps:]
     assert steps, "no timed steps left after --skip-steps"
     mark_idx = {i for m in merged for i in m}
+    if args.list:
+        with open(args.list, "w") as f:
+            for pi, phase in enumerate(("encode", "decode")):
+                t0, t1 = steps[-1][pi]
+                cur_end = t0
+                for i, (s_, e_, n_) in enumerate(rows):
+                    if i in mark_idx or s_ < t0 or e_ > t1:
+                        continue
+                    f.write(f"{phase} {(s_ - t0) / 1e3:10.1f} {max(0, s_ - cur_end) / 1e3:8.1f} {(e_ - s_) / 1e3:8.1f}  {n_[:110]}\n")
+                    cur_end = max(cur_end, e_)
+                f.write(f"{phase} {(t1 - t0) / 1e3:10.1f} {max(0, t1 - cur_end) / 1e3:8.1f} {0.0:8.1f}  <phase end>\n")
     out = {"steps": len(steps), "phases": {}}
     for pi, phase in enumerate(("encode", "decode")):
         wall = busy = 0.0
