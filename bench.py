@@ -608,6 +608,22 @@ def main():
                     roofline["frac_at_delivered_clock"] = achieved / (peak * val["mean_clock_GHz"] / 2.4)
                     roofline["clock_source"] = {"file": cj["_file"], "taken_at_commit": cj.get("commit"),
                                                 "how": "GRBM_GUI_ACTIVE / launch duration, separate --pmc pass"}
+        # the matrix pipe seen by the hardware counters: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x SIMDs) of
+        # this kernel template, from a separate rocprofv3 --pmc pass of this command (tools/gpu_pmc_job.sh -> tools/pmc_mfma.py)
+        mj = latest_profile("mfma_util")
+        if args.workload == "config2" and "[bf16]" not in dom_name and "[x3]" not in dom_name and mj is not None:
+            want = dom_name.replace(" ", "").rstrip(">")
+            for key, val in mj.get("kernels", {}).items():
+                if key.startswith(want):
+                    roofline["mfma_busy_frac"] = val["mfma_busy_frac"]
+                    roofline["mfma_busy_frac_of_2p4ghz"] = val["mfma_busy_frac_of_2p4ghz"]
+                    roofline["mfma_counter_source"] = {
+                        "file": mj["_file"], "taken_at_commit": mj.get("commit"),
+                        "kernel_source_unchanged_since": mj.get("kernel_source_sha256") == kernel_source_sha256(),
+                        "how": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), one rocprofv3 --pmc pass with "
+                               "--kernel-trace; busy share of SIMD-cycles at the delivered clock, and the same cycles against 2.4 GHz; "
+                               "replayed from the committed file, not measured in this run"}
+                    break
     if args.breakdown and rank == 0:
         tot_ms = sum(c["ms"] for c in classes.values())
         for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
