@@ -541,7 +541,7 @@ def main():
     pop_cache = {}
 
     def active_slots(gmask, n_out):
-        """sum over 64-row groups of the number of kernel offsets the group executes"""
+        """issued rows / 32: sum over MFMA row tiles of the number of kernel offsets the tile executes (a 16-row tile = 1/2)"""
         if gmask is None:
             return (n_out + 31) // 32
         key = gmask.data_ptr()
@@ -550,7 +550,8 @@ def main():
             pop_cache[key] = int(((gmask.cpu().numpy().astype(np.int64) + 31) // 32).sum())
         if key not in pop_cache:
             # counted on the host: 27 tiny device reductions per map would fill the kernel trace
-            pop_cache[key] = int(np.unpackbits(gmask.cpu().numpy().view(np.uint8)).sum())
+            bits = int(np.unpackbits(gmask.cpu().numpy().view(np.uint8)).sum())
+            pop_cache[key] = bits / 2.0 if gmask.numel() == (n_out + 15) // 16 and n_out > 16 else bits
         return pop_cache[key]
 
     launches = []

@@ -125,7 +125,12 @@ int pcc_pair_count(const uint32_t* row_mask, int64_t n_out, int64_t* pair_count,
  *   order[p]        = output row executed at position p
  *   nbr_sorted[p,:] = nbr[order[p],:]
  *   group_mask32[g] = OR of row_mask over positions 32g .. 32g+31
- * scratch_bytes from pcc_order_scratch_bytes(n). */
+ * scratch_bytes from pcc_order_scratch_bytes(n).
+ *   pcc_order_rows_by_mask16 additionally writes group_mask16[g] = OR over positions 16g .. 16g+15 (may be NULL): the
+ *   masks of the 16-row MFMA tiles of pcc_conv_fwd16. */
+int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
+                             int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
+                             uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes, void* stream);
 int64_t pcc_order_scratch_bytes(int64_t n);
 int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int64_t n,
                            int32_t block_log2, int32_t tensor_stride, const int32_t* nbr, int32_t K,
@@ -157,6 +162,14 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
                  const float* bias, const int32_t* nbr, const int32_t* order,
                  const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
                  int32_t act, const float* film, const float* residual, void* stream);
+
+/* pcc_conv_fwd with 16-row MFMA tiles (v_mfma_f32_16x16x4_f32) on the MFMA path: a 16-row half of a tile skips the
+ * offsets none of its rows has (group_mask16 from pcc_order_rows_by_mask16; NULL = pcc_conv_fwd).  Results are
+ * bit-identical to pcc_conv_fwd's — one 16x16x4 MFMA runs the same fp32 chain as two chained 32x32x2
+ * (tools/micro/mfma_shapes_bitwise.hip) — at the same MFMA throughput; mask-diverse row sets execute fewer empty tiles. */
+int pcc_conv_fwd16(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
+                   const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, const uint32_t* group_mask16, int32_t K,
+                   float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
 
 /* Convolution in the map's own row order with compacted offset lists (csrc/conv_co.hip) — the default of the fp32
  * inference path for kernel maps (cin % 32 == 0, cout % 64 == 0).  pcc_compact_map turns a kernel map nbr [n_out, K] into,

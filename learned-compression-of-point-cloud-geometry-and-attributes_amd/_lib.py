@@ -34,6 +34,10 @@ SIGNATURES = {
     "pcc_order_scratch_bytes": (c_i64, [c_i64]),
     "pcc_order_rows_by_mask": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_order_rows_by_mask16": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_conv_fwd16": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
+                               c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_conv_fwd": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                              c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_compact_map_groups": (c_i64, [c_i64]),

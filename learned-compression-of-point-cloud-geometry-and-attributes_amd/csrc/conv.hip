@@ -22,6 +22,7 @@
 
 namespace pcc {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,6 +35,7 @@ struct ConvArgs {
     const int32_t* nbr;   // [n_out, K] or null (identity); permuted by `order` on the MFMA path
     const int32_t* order;   // [n_out] execution position -> output row, or null (natural order)
     const uint32_t* gmask;  // [ceil(n_out/32)] offsets live per 32 positions, or null (all live)
+    const uint32_t* gmask16;  // [ceil(n_out/16)] offsets live per 16 positions: the 16-row-tile kernels (M16), else null
     float* fout;
     const float* film;      // [n_out, 2*cout] or null
     const float* residual;  // [n_out, cout] or null
@@ -435,9 +437,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // leading one — lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, in that fixed order — go through v_mfma_f32_32x32x16_bf16
 // with fp32 accumulation: 12 MFMAs of 8 passes per 32 x 32 x 32 block instead of 16 of 16 (3/8 of the matrix-pipe time),
 // every bf16 product exact in fp32, the dropped terms below 3 x 2^-24 of |x||w| — the size of an fp32 rounding.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false>
+// M16 (fp32 only, pcc_conv_fwd16): the MFMA tiles are 16 rows x 16 columns (v_mfma_f32_16x16x4_f32) instead of 32 x 32
+// (v_mfma_f32_32x32x2_f32), and a 16-ROW half of a wave's rows skips the offsets none of its rows has (group masks per 16
+// positions).  One 16x16x4 contracts four channels in the order two chained 32x32x2 do — lane group kq = lane >> 4 supplies
+// channel 8 kk + 4 (kq & 1) + 2 p + (kq >> 1) of sub-block kk for p = 0, 1 — and the hardware's chain is the same fused
+// multiply-add sequence either way (tools/micro/mfma_shapes_bitwise.hip: 0 of 5.1 M elements differ), so an element's
+// result is bit-identical to the 32-row kernels'.  Same throughput per FLOP (32 cycles per 2048 FLOP); what it buys is
+// fill on mask-diverse sets: issued / useful 1.80 -> 1.60 on the sparse sets an untrained decoder keeps, 1.08 -> 1.04 on
+// surfaces (tools/order_experiment.py); what it costs is twice the LDS fragment reads (8 bytes per lane instead of 16).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false, bool M16 = false>
 __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)           // the buffer builtins exist in the device pass only; the host pass needs just the stub
+    static_assert(!M16 || (!BF16 && !X3), "16-row tiles exist for the fp32 kernel only");
     constexpr int RPT = BM / 32;              // gather DMAs per thread and step (8 lanes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
@@ -467,6 +478,7 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
     const int K = a.K;
 
     uint32_t tmask, mmask[MT];
+    [[maybe_unused]] uint32_t hmask[MT][2];          // M16: offsets live per 16-row half of my 32-row tiles
     {
         const uint32_t all = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
         if (a.gmask) {
@@ -480,16 +492,30 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
                 const int64_t g = g0 + (wrow >> 5) + m;
                 const uint32_t v = (g < ng) ? (a.gmask[g] & all) : 0u;
                 mmask[m] = __builtin_amdgcn_readfirstlane(v);
+                if constexpr (M16) {
+                    const int64_t ng16 = (a.n_out + 15) >> 4;
+#pragma unroll
+                    for (int hm = 0; hm < 2; ++hm) {
+                        const int64_t g16 = 2 * g + hm;
+                        const uint32_t v16 = (a.gmask16 && g16 < ng16) ? (a.gmask16[g16] & all) : (a.gmask16 ? 0u : v);
+                        hmask[m][hm] = __builtin_amdgcn_readfirstlane(v16);
+                    }
+                }
             }
         } else {
             tmask = all;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) mmask[m] = all;
+            for (int m = 0; m < MT; ++m) {
+                mmask[m] = all;
+                if constexpr (M16) hmask[m][0] = hmask[m][1] = all;
+            }
         }
         tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
 
     f32x16 acc[MT][NT];
+    // M16: the same 16 registers per 32 x 32 block, as four 16 x 16 blocks (half hm, column half cb) of 4 registers:
+    // acc[m][n][4 (2 hm + cb) + reg] = D[row 16 hm + 4 (lane >> 4) + reg][column 16 cb + (lane & 15)]
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -683,8 +709,88 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             }
             __builtin_amdgcn_s_setprio(0);
         };
+        // M16 fragments.  Lane (j = lane & 15, kq = lane >> 4) reads, for sub-block kk, the floats 0 / 2 (kq < 2) or 1 / 3
+        // (kq >= 2) of the 16-B chunk 2 kk + (kq & 1) — of row 16 hm + j of a 32-row tile, and of weight column 16 cb + j of a
+        // 32-column tile: one ds_read2_b32 per operand block and sub-block, no selects.
+        [[maybe_unused]] uint32_t a16_addr[2][4], w16_addr[2];
+        if constexpr (M16) {
+            const int j16 = lane & 15, kq = lane >> 4;
+            const int R = wrow + j16;                      // + 16 hm + 32 m, which leave the swizzle (R >> 1) & 7 unchanged
+            const int sw16 = (R >> 1) & 7;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    a16_addr[b][kk] = (uint32_t)((b * A_ELEMS + R * 32 + (((2 * kk + (kq & 1)) ^ sw16) * 4) + (kq >> 1)) * 4);
+                w16_addr[b] = (uint32_t)((2 * A_ELEMS + b * W_ELEMS + ((kq & 1) * BN + wcol + j16) * 4 + (kq >> 1)) * 4);
+            }
+        }
+        auto a16_at = [&](uint32_t base, int m, int hm) -> uint32_t { return base + (uint32_t)((16 * hm + 32 * m) * 32 * 4); };
+        auto lds2 = [&](uint32_t addr) {                                     // floats at addr and addr + 8
+            const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + addr);
+            return f32x2{q[0], q[2]};
+        };
+        // LIVE: bit 2 m + hm = half hm of 32-row tile m takes this offset
+        auto compute_live16 = [&](auto bufc, auto live_tag) {
+            constexpr int buf = decltype(bufc)::value;
+            constexpr unsigned LIVE = decltype(live_tag)::value;
+            f32x2 av[2][MT][2], bv[2][NT][2];
+            __builtin_amdgcn_s_setprio(1);
+            auto load = [&](int slot, int kk) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int hm = 0; hm < 2; ++hm)
+                        if ((LIVE >> (2 * m + hm)) & 1u) av[slot][m][hm] = lds2(a16_at(a16_addr[buf][kk], m, hm));
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+                        bv[slot][n][cb] = lds2(w16_addr[buf] + (uint32_t)((2 * kk * BN + 32 * n + 16 * cb) * 16));
+            };
+            load(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int cbf = kk & 1, nb = cbf ^ 1;
+                if (kk + 1 < 4) load(nb, kk + 1);
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int hm = 0; hm < 2; ++hm)
+#pragma unroll
+                            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                                for (int cb = 0; cb < 2; ++cb)
+                                    if ((LIVE >> (2 * m + hm)) & 1u) {
+                                        f32x4 c;
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) c[e] = acc[m][n][4 * (2 * hm + cb) + e];
+                                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cbf][m][hm][p], bv[cbf][n][cb][p], c, 0, 0, 0);
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) acc[m][n][4 * (2 * hm + cb) + e] = c[e];
+                                    }
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
         auto compute = [&](auto bufc, unsigned live) {        // live: wave-uniform, bit m = 32-row tile m has this offset
-            if constexpr (MT == 1) {
+            if constexpr (M16) {                              // here: bit 2 m + hm = 16-row half hm of tile m
+                switch (live) {
+#define PCC_L16(V) case V: compute_live16(bufc, std::integral_constant<unsigned, V>{}); break;
+                    PCC_L16(1u) PCC_L16(2u) PCC_L16(3u)
+                    default:
+                        if constexpr (MT == 2) {
+                            switch (live) {
+                                PCC_L16(4u) PCC_L16(5u) PCC_L16(6u) PCC_L16(7u) PCC_L16(8u) PCC_L16(9u) PCC_L16(10u) PCC_L16(11u)
+                                PCC_L16(12u) PCC_L16(13u) PCC_L16(14u) PCC_L16(15u)
+                                default: break;
+                            }
+                        }
+                        break;
+#undef PCC_L16
+                }
+            } else if constexpr (MT == 1) {
                 if (live) compute_live(bufc, std::integral_constant<unsigned, 1u>{});
             } else {
                 if (live == 3u) compute_live(bufc, std::integral_constant<unsigned, 3u>{});
@@ -708,7 +814,10 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             const int kn2 = rem2 ? __builtin_ctz(rem2) : (knext >= 0 ? knext : k);
             unsigned live = 0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) live |= ((mmask[m] >> k) & 1u) << m;
+            for (int m = 0; m < MT; ++m) {
+                if constexpr (M16) live |= (((hmask[m][0] >> k) & 1u) | (((hmask[m][1] >> k) & 1u) << 1)) << (2 * m);
+                else live |= ((mmask[m] >> k) & 1u) << m;
+            }
             static_for<0, CCH>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 constexpr int buf = (P + c) & 1;
@@ -742,16 +851,18 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
     }
 
     // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r] per 32x32 tile
+    // (M16: register 4 (2 hm + cb) + e = D[row 16 hm + 4 (lane >> 4) + e][col 16 cb + (lane & 15)])
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int col = nt * BN + wcol + 32 * n + r;
-            if (col >= a.cout) continue;
-            const float bcol = a.bias ? a.bias[col] : 0.0f;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int64_t pos = row0 + wrow + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                const int col = nt * BN + wcol + 32 * n + (M16 ? 16 * ((reg >> 2) & 1) + (lane & 15) : r);
+                if (col >= a.cout) continue;
+                const float bcol = a.bias ? a.bias[col] : 0.0f;
+                const int64_t pos = row0 + wrow + 32 * m + (M16 ? 16 * (reg >> 3) + 4 * (lane >> 4) + (reg & 3)
+                                                                : (reg & 3) + 8 * (reg >> 2) + 4 * h);
                 if (pos >= a.n_out) continue;
                 const int64_t row = a.order ? a.order[pos] : pos;
                 float v = acc[m][n][reg] + bcol;
@@ -922,10 +1033,10 @@ static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     return PCC_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false, bool M16 = false>
 static int launch_mfma_buf_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16, X3>;
+    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16, X3, M16>;
     const int lds = conv_lds_bytes<BM, BN, X3>();
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -949,6 +1060,16 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_mfma(const ConvArgs& a, hipStream_t st) {
     static int path = -1;      // PCC_CONV_PATH=global forces the 64-bit-addressed kernel (testing; the >= 4 GiB fallback)
     if (path < 0) { const char* e = getenv("PCC_CONV_PATH"); path = (e && e[0] == 'g') ? 1 : 0; }
+    // 16-row MFMA tiles (pcc_conv_fwd16: a.gmask16 set): instantiated for the channel counts the codec has, maps only
+    if (path == 0 && a.gmask16 && a.nbr && fits_buffer_path(a)) {
+        switch (a.cin / 32) {
+            case 1: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 1, true, false, false, true>(a, st);
+            case 2: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 2, true, false, false, true>(a, st);
+            case 4: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 4, true, false, false, true>(a, st);
+            case 6: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 6, true, false, false, true>(a, st);
+            default: break;          // other widths: the 32-row kernels below (bit-identical)
+        }
+    }
     if (path == 0 && fits_buffer_path(a)) {
 #define PCC_BUF_CASE(C)                                                                                        \
     case C:                                                                                                    \
@@ -1061,7 +1182,7 @@ int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
     a.fin = reinterpret_cast<const float*>(fin); a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
-    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout; a.film = film; a.residual = residual;
+    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.gmask16 = nullptr; a.fout = fout; a.film = film; a.residual = residual;
     a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 1;
     a.debug = 0;
     PCC_REQUIRE((uint64_t)n_in * cin * 2 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB,
@@ -1101,7 +1222,7 @@ int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t*
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
     a.fin = fin; a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
-    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout; a.film = film; a.residual = residual;
+    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.gmask16 = nullptr; a.fout = fout; a.film = film; a.residual = residual;
     a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 0;
     a.debug = 0;
     PCC_REQUIRE((uint64_t)n_in * cin * 4 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB && (uint64_t)K * cin * a.coutp * 6 <= BUF_OOB,
@@ -1147,13 +1268,20 @@ int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int3
 int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
                  const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                  int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
+    return pcc_conv_fwd16(fin, n_in, cin, w, w_packed, bias, nbr, order, group_mask32, nullptr, K, fout, n_out, cout, act, film, residual,
+                          stream);
+}
+
+int pcc_conv_fwd16(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
+                   const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, const uint32_t* group_mask16, int32_t K,
+                   float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
     PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd: K=%d out of range", K);
     PCC_REQUIRE(cin % 32 != 0 || cin <= 256, "pcc_conv_fwd: MFMA path supports cin <= 256 (got %d)", cin);
     PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd: nbr == NULL needs K == 1 and n_in == n_out");
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation %d", act);
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
-    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout;
+    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.gmask16 = group_mask16; a.fout = fout;
     a.film = film; a.residual = residual; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout;
     a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 0;
     { static int dbg = -1; if (dbg < 0) { const char* e = getenv("PCC_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }

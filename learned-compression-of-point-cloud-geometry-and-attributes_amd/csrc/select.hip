@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void order_apply_kernel(const int32_t* __restr
                                                           const uint32_t* __restrict__ row_mask,
                                                           const int32_t* __restrict__ nbr, int64_t n, int K,
                                                           int32_t* __restrict__ nbr_sorted,
-                                                          uint32_t* __restrict__ group_mask32) {
+                                                          uint32_t* __restrict__ group_mask32,
+                                                          uint32_t* __restrict__ group_mask16) {
     __shared__ int32_t src_row[256];
     const int64_t r0 = (int64_t)blockIdx.x * 256;
     const int64_t i = r0 + threadIdx.x;
@@ -259,7 +260,9 @@ __global__ __launch_bounds__(256) void order_apply_kernel(const int32_t* __restr
     src_row[threadIdx.x] = src;
     uint32_t m = (i < n) ? row_mask[src] : 0u;
 #pragma unroll
-    for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
+    for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
+    if (group_mask16 && i < n && (threadIdx.x & 15) == 0) group_mask16[i >> 4] = m;      // 16-row MFMA tiles (pcc_conv_fwd16)
+    m |= __shfl_xor(m, 16, 64);
     if (i < n && (threadIdx.x & 31) == 0) group_mask32[i >> 5] = m;
     __syncthreads();
     const int rows = (int)((n - r0 < 256) ? (n - r0) : 256);
@@ -304,6 +307,13 @@ int64_t pcc_order_scratch_bytes(int64_t n) { return pcc_sort_scratch_bytes(n); }
 int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
                            int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
                            uint32_t* group_mask32, void* scratch, int64_t scratch_bytes, void* stream) {
+    return pcc_order_rows_by_mask16(row_mask, coords, n, block_log2, tensor_stride, nbr, K, order, nbr_sorted, group_mask32, nullptr,
+                                    scratch, scratch_bytes, stream);
+}
+
+int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
+                             int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
+                             uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes, void* stream) {
     if (n <= 0) return PCC_OK;
     PCC_REQUIRE(n < (1ll << 31), "pcc_order_rows_by_mask: too many rows");
     PCC_REQUIRE(K >= 1 && K <= 27, "pcc_order_rows_by_mask: K out of range");
@@ -328,7 +338,7 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     if (legacy == 2) {
         hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, n);
         hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
-                           nbr_sorted, group_mask32);
+                           nbr_sorted, group_mask32, group_mask16);
         PCC_LAUNCH_CHECK();
         return PCC_OK;
     }
@@ -351,7 +361,7 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     }
     if (rc) return rc;
     hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
-                       nbr_sorted, group_mask32);
+                       nbr_sorted, group_mask32, group_mask16);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

@@ -219,13 +219,20 @@ class CoordMap:
         order = torch.empty(n_out, dtype=torch.int32, device=dev)
         nbr_sorted = torch.empty_like(nbr)
         gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
+        gmask16 = torch.empty((n_out + 15) // 16, dtype=torch.int32, device=dev)      # the 16-row tiles of pcc_conv_fwd16
         nbytes = L.pcc_order_scratch_bytes(n_out)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(L.pcc_order_rows_by_mask(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
-                                       ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(scratch), nbytes,
-                                       _lib.stream()))
+        check(L.pcc_order_rows_by_mask16(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
+                                         ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch), nbytes,
+                                         _lib.stream()))
         self._cache[key] = (None if out_map is self else out_map, nbr_sorted, order, gmask, pairs)
+        self._cache[("gmask16",) + key[1:]] = gmask16
         return nbr_sorted, order, gmask, pairs
+
+    def group_mask16(self, out_map, ksize, transposed=False):
+        """per-16-position offset masks of the ordered kernel map (built with it), for the 16-row-tile convolution"""
+        self.ordered_kernel_map(out_map, ksize, transposed)
+        return self._cache[("gmask16", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)]
 
     def compact_kernel_map(self, out_map, ksize, transposed=False):
         """Kernel map as per-group compacted offset lists (csrc/conv_co.hip): (ent_in int32 [G, K, 256], ent_row4 int32
@@ -495,8 +502,11 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         check(L.pcc_conv_fwd_x3(ptr(x_feats), x_feats.shape[0], cin, ptr(layer.weights_x3(out_channels)), ptr(bias), ptr(nbr),
                                 ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     else:
-        check(L.pcc_conv_fwd(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask), K,
-                             ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+        g16 = in_map.group_mask16(out_map, ksize, transposed) if (CONV_T16 and gmask is not None) else None
+        check(L.pcc_conv_fwd16(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask),
+                               ptr(g16), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
+        if prof is not None and g16 is not None and cin // 32 in (1, 2, 4, 6):
+            gmask = g16                              # the profiler's issued-row count follows the tile height
     if prof is not None:
         ev1.record()
         name = conv_kernel_name(cin, cout, n_out, nbr is not None)
@@ -548,6 +558,16 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
         ev1.record()
         prof.append((f"narrow_head<{cin}>", cin, cout, pairs, n_out, ev0, ev1, None))
     return out
+
+
+# 16-row MFMA tiles (v_mfma_f32_16x16x4_f32, csrc/conv.hip M16) for the fp32 inference convolutions over kernel maps: bit-identical
+# to the 32-row tiles, fewer empty tiles on mask-diverse row sets.  PCC_CONV_T16=0 takes the 32-row kernels (A/B runs).
+CONV_T16 = os.environ.get("PCC_CONV_T16", "1") == "1"
+
+
+def set_conv_t16(enabled):
+    global CONV_T16
+    CONV_T16 = bool(enabled)
 
 
 # Experimental, off by default: PCC_CONV_CO=1 / set_conv_co(True) runs the wide fp32 inference convolutions on compacted
