@@ -513,15 +513,22 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
         tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
 
-    f32x16 acc[MT][NT];
+    [[maybe_unused]] f32x16 acc[MT][NT];
     // M16: the same 16 registers per 32 x 32 block, as four 16 x 16 blocks (half hm, column half cb) of 4 registers:
-    // acc[m][n][4 (2 hm + cb) + reg] = D[row 16 hm + 4 (lane >> 4) + reg][column 16 cb + (lane & 15)]
+    // acc16[m][hm][n][cb][reg] = D[row 16 hm + 4 (lane >> 4) + reg][column 16 cb + (lane & 15)]
+    [[maybe_unused]] f32x4 acc16[MT][2][NT][2];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int n = 0; n < NT; ++n) {
+            if constexpr (M16) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+                for (int q = 0; q < 4; ++q) acc16[m][q >> 1][n][q & 1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
+            }
+        }
 
     if (tmask != 0u) {
         __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
@@ -730,18 +737,18 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + addr);
             return f32x2{q[0], q[2]};
         };
-        // LIVE: bit 2 m + hm = half hm of 32-row tile m takes this offset
-        auto compute_live16 = [&](auto bufc, auto live_tag) {
+        // One 32-row tile m of the wave at a time; LIVE: bit hm = its 16-row half hm takes this offset (three straight-line
+        // variants per tile; all 15 combinations of a two-tile wave in one block overflowed the compiler's register promotion)
+        auto compute_live16 = [&](auto bufc, auto mc, auto live_tag) {
             constexpr int buf = decltype(bufc)::value;
+            constexpr int m = decltype(mc)::value;
             constexpr unsigned LIVE = decltype(live_tag)::value;
-            f32x2 av[2][MT][2], bv[2][NT][2];
+            f32x2 av[2][2], bv[2][NT][2];
             __builtin_amdgcn_s_setprio(1);
             auto load = [&](int slot, int kk) {
 #pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int hm = 0; hm < 2; ++hm)
-                        if ((LIVE >> (2 * m + hm)) & 1u) av[slot][m][hm] = lds2(a16_at(a16_addr[buf][kk], m, hm));
+                for (int hm = 0; hm < 2; ++hm)
+                    if ((LIVE >> hm) & 1u) av[slot][hm] = lds2(a16_at(a16_addr[buf][kk], m, hm));
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
@@ -756,40 +763,26 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int p = 0; p < 2; ++p)
 #pragma unroll
-                    for (int m = 0; m < MT; ++m)
+                    for (int hm = 0; hm < 2; ++hm)
 #pragma unroll
-                        for (int hm = 0; hm < 2; ++hm)
+                        for (int n = 0; n < NT; ++n)
 #pragma unroll
-                            for (int n = 0; n < NT; ++n)
-#pragma unroll
-                                for (int cb = 0; cb < 2; ++cb)
-                                    if ((LIVE >> (2 * m + hm)) & 1u) {
-                                        f32x4 c;
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) c[e] = acc[m][n][4 * (2 * hm + cb) + e];
-                                        c = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cbf][m][hm][p], bv[cbf][n][cb][p], c, 0, 0, 0);
-#pragma unroll
-                                        for (int e = 0; e < 4; ++e) acc[m][n][4 * (2 * hm + cb) + e] = c[e];
-                                    }
+                            for (int cb = 0; cb < 2; ++cb)
+                                if ((LIVE >> hm) & 1u)
+                                    acc16[m][hm][n][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cbf][hm][p], bv[cbf][n][cb][p],
+                                                                                               acc16[m][hm][n][cb], 0, 0, 0);
             }
             __builtin_amdgcn_s_setprio(0);
         };
+        auto compute16_tile = [&](auto bufc, auto mc, unsigned lv) {
+            if (lv == 3u) compute_live16(bufc, mc, std::integral_constant<unsigned, 3u>{});
+            else if (lv == 1u) compute_live16(bufc, mc, std::integral_constant<unsigned, 1u>{});
+            else if (lv == 2u) compute_live16(bufc, mc, std::integral_constant<unsigned, 2u>{});
+        };
         auto compute = [&](auto bufc, unsigned live) {        // live: wave-uniform, bit m = 32-row tile m has this offset
             if constexpr (M16) {                              // here: bit 2 m + hm = 16-row half hm of tile m
-                switch (live) {
-#define PCC_L16(V) case V: compute_live16(bufc, std::integral_constant<unsigned, V>{}); break;
-                    PCC_L16(1u) PCC_L16(2u) PCC_L16(3u)
-                    default:
-                        if constexpr (MT == 2) {
-                            switch (live) {
-                                PCC_L16(4u) PCC_L16(5u) PCC_L16(6u) PCC_L16(7u) PCC_L16(8u) PCC_L16(9u) PCC_L16(10u) PCC_L16(11u)
-                                PCC_L16(12u) PCC_L16(13u) PCC_L16(14u) PCC_L16(15u)
-                                default: break;
-                            }
-                        }
-                        break;
-#undef PCC_L16
-                }
+                compute16_tile(bufc, std::integral_constant<int, 0>{}, live & 3u);
+                if constexpr (MT == 2) compute16_tile(bufc, std::integral_constant<int, 1>{}, (live >> 2) & 3u);
             } else if constexpr (MT == 1) {
                 if (live) compute_live(bufc, std::integral_constant<unsigned, 1u>{});
             } else {
@@ -865,7 +858,7 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
                                                                 : (reg & 3) + 8 * (reg >> 2) + 4 * h);
                 if (pos >= a.n_out) continue;
                 const int64_t row = a.order ? a.order[pos] : pos;
-                float v = acc[m][n][reg] + bcol;
+                float v = (M16 ? acc16[m][reg >> 3][n][(reg >> 2) & 1][reg & 3] : acc[m][n][reg]) + bcol;
                 if (a.film) {
                     const float* fr = a.film + row * (2 * (int64_t)a.cout);
                     v = v * fr[col] + fr[a.cout + col];
@@ -1060,13 +1053,17 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_mfma(const ConvArgs& a, hipStream_t st) {
     static int path = -1;      // PCC_CONV_PATH=global forces the 64-bit-addressed kernel (testing; the >= 4 GiB fallback)
     if (path < 0) { const char* e = getenv("PCC_CONV_PATH"); path = (e && e[0] == 'g') ? 1 : 0; }
-    // 16-row MFMA tiles (pcc_conv_fwd16: a.gmask16 set): instantiated for the channel counts the codec has, maps only
+    // 16-row MFMA tiles (pcc_conv_fwd16: a.gmask16 set): instantiated for the channel counts the codec has, maps only.  Waves
+    // that own two 32-row tiles (128-row workgroups) take them up to 64 input channels: with four or six channel chunks of
+    // straight-line steps x two tiles x three liveness variants the compiler stops promoting the accumulators to registers
+    // (240-368 bytes of scratch per lane, 20x slower) — those launches keep the 32-row kernels, bit-identical.
+    constexpr bool TWO_TILES = (BM / WAVES_M) == 64;
     if (path == 0 && a.gmask16 && a.nbr && fits_buffer_path(a)) {
         switch (a.cin / 32) {
             case 1: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 1, true, false, false, true>(a, st);
             case 2: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 2, true, false, false, true>(a, st);
-            case 4: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 4, true, false, false, true>(a, st);
-            case 6: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 6, true, false, false, true>(a, st);
+            case 4: if constexpr (!TWO_TILES) return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 4, true, false, false, true>(a, st); else break;
+            case 6: if constexpr (!TWO_TILES) return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 6, true, false, false, true>(a, st); else break;
             default: break;          // other widths: the 32-row kernels below (bit-identical)
         }
     }

@@ -505,7 +505,9 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         g16 = in_map.group_mask16(out_map, ksize, transposed) if (CONV_T16 and gmask is not None) else None
         check(L.pcc_conv_fwd16(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask),
                                ptr(g16), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
-        if prof is not None and g16 is not None and cin // 32 in (1, 2, 4, 6):
+        coutp = (cout + 31) // 32 * 32
+        two_tiles = coutp % 128 != 0                 # 128 x 64 and 128 x 32 workgroups: two 32-row tiles per wave (csrc/conv.hip)
+        if prof is not None and g16 is not None and (cin // 32 in (1, 2) or (cin // 32 in (4, 6) and not (two_tiles and coutp % 64 == 0))):
             gmask = g16                              # the profiler's issued-row count follows the tile height
     if prof is not None:
         ev1.record()
@@ -560,9 +562,12 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
     return out
 
 
-# 16-row MFMA tiles (v_mfma_f32_16x16x4_f32, csrc/conv.hip M16) for the fp32 inference convolutions over kernel maps: bit-identical
-# to the 32-row tiles, fewer empty tiles on mask-diverse row sets.  PCC_CONV_T16=0 takes the 32-row kernels (A/B runs).
-CONV_T16 = os.environ.get("PCC_CONV_T16", "1") == "1"
+# Experimental, off by default: PCC_CONV_T16=1 / set_conv_t16(True) gives the fp32 inference convolutions over kernel maps 16-row MFMA
+# tiles (v_mfma_f32_16x16x4_f32, csrc/conv.hip M16).  Bit-identical to the 32-row tiles (tests/test_conv_t16.py) and 11 % fewer
+# issued rows on the sparse sets an untrained decoder keeps (issued / useful 1.67 -> 1.48 on the 265 k-row layers), but the
+# fragment reads double in count and land 2-way on the LDS banks, which costs the same 5-10 % in issue rate: 77.4 ms of
+# convolutions per config-2 frame against 74.9 (round 3).
+CONV_T16 = os.environ.get("PCC_CONV_T16", "0") == "1"
 
 
 def set_conv_t16(enabled):
