@@ -59,6 +59,7 @@ class CoordinateRangeError(ValueError):
 
 
 COUNT_ARMED, COUNT_ERR_RANGE = -1, -2            # PCC_COUNT_ERR_RANGE of include/pcc_hip.h
+_POLL_YIELD = os.environ.get("PCC_COUNT_POLL_YIELD", "1") == "1"      # 0: spin without yielding the interpreter lock (A/B)
 
 
 def _read_count(buf, device):
@@ -73,7 +74,8 @@ def _read_count(buf, device):
         if time.perf_counter() > deadline:        # not visible yet (or the stream is behind): fall back to a real wait
             torch.cuda.current_stream(device).synchronize()
             break
-        time.sleep(0)
+        if _POLL_YIELD:
+            time.sleep(0)
     n = int(arr[0])
     if n == COUNT_ERR_RANGE:
         raise CoordinateRangeError("libpcc_hip: a voxel coordinate is outside the supported range (|c| <= 32000, batch index "
