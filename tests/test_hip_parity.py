@@ -585,3 +585,53 @@ def test_gaussian_conditional_packed_planes(pcc, oracle_codec):
         back = gc.decompress_features(a, p_sorted, c)
         want = torch.round(feats.index_select(0, perm.long()) - p_sorted[:, c:]) + p_sorted[:, c:]
         assert torch.equal(back, want)
+
+
+_THIN_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+import pcc_amd
+from pcc_amd import sparse as sp
+torch.manual_seed(5)
+rng = np.random.default_rng(2)
+p = pcc_amd.synthetic.sphere_shell(64, 27.0, 0.9)[:, :3]
+c = np.concatenate([np.zeros((p.shape[0], 1)), p], axis=1).astype(np.int32)
+c = c[rng.permutation(c.shape[0])]
+sub = c[rng.random(c.shape[0]) < 0.4]
+h = hashlib.sha256()
+for coords in (c, sub, c[:70], c[:1]):
+    n = coords.shape[0]
+    m = pcc_amd.CoordMap(torch.from_numpy(coords).cuda(), 1)
+    for cin, cout in ((2, 128), (4, 64), (2, 64), (16, 32), (1, 32), (8, 96)):
+        layer = pcc_amd.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).cuda()
+        x = pcc_amd.SparseTensor(torch.randn(n, cin).cuda(), coordinate_map=m)
+        film, res = torch.randn(n, 2 * cout).cuda(), torch.randn(n, cout).cuda()
+        for kw in ({{}}, dict(act=sp.ACT_RELU, residual=res), dict(act=sp.ACT_LRELU, film=film, residual=res)):
+            h.update(layer(x, **kw).F.cpu().numpy().tobytes())
+    # strided and transposed maps (K = 27 and K = 8) with thin inputs
+    m2 = pcc_amd.CoordMap(torch.from_numpy(coords * np.array([1, 2, 2, 2], np.int32)).cuda(), 2)
+    x2 = pcc_amd.SparseTensor(torch.randn(n, 2).cuda(), coordinate_map=m2)
+    for layer in (pcc_amd.MinkowskiConvolution(2, 64, kernel_size=3, stride=2, bias=True, dimension=3),
+                  pcc_amd.MinkowskiGenerativeConvolutionTranspose(2, 32, kernel_size=2, stride=2, bias=True, dimension=3),
+                  pcc_amd.MinkowskiGenerativeConvolutionTranspose(2, 64, kernel_size=3, stride=2, bias=True, dimension=3)):
+        h.update(layer.cuda()(x2).F.cpu().numpy().tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_thin_row_kernel_equals_thin_kernel_bitwise():
+    """thin inputs, wide outputs (2 -> 128, 4 -> 64, ...): conv_thin_row_kernel (a lane = a row, a wave = 32 output channels,
+    weights as scalar operands; the default) against conv_thin_kernel (PCC_THIN_ROW=0): the same fused multiply-adds in the
+    same order, so the same bits — over dense / sparse / 70-row / one-row sets, every epilogue, strided and transposed maps"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for flag in ("1", "0"):
+        env = dict(os.environ, PCC_THIN_ROW=flag)
+        r = subprocess.run([sys.executable, "-c", _THIN_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
