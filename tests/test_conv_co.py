@@ -15,6 +15,14 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True)
+def _inference_mode():
+    """these tests are about the INFERENCE kernels: with gradients enabled a layer with trainable parameters takes the
+    autograd path (conv_train), which never dispatches to the kernels under test"""
+    with torch.no_grad():
+        yield
+
+
 def dev(a, dtype=None):
     t = torch.as_tensor(a)
     if dtype is not None:

@@ -594,6 +594,7 @@ sys.path.insert(0, {root!r})
 import pcc_amd
 from pcc_amd import sparse as sp
 torch.manual_seed(5)
+torch.set_grad_enabled(False)          # the inference kernels (with gradients on, trainable layers take the autograd path)
 rng = np.random.default_rng(2)
 p = pcc_amd.synthetic.sphere_shell(64, 27.0, 0.9)[:, :3]
 c = np.concatenate([np.zeros((p.shape[0], 1)), p], axis=1).astype(np.int32)
