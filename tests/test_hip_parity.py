@@ -604,7 +604,7 @@ h = hashlib.sha256()
 for coords in (c, sub, c[:70], c[:1]):
     n = coords.shape[0]
     m = pcc_amd.CoordMap(torch.from_numpy(coords).cuda(), 1)
-    for cin, cout in ((2, 128), (4, 64), (2, 64), (16, 32), (1, 32), (8, 96)):
+    for cin, cout in ((2, 128), (4, 64), (2, 64), (16, 32), (1, 32), (8, 64)):
         layer = pcc_amd.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).cuda()
         x = pcc_amd.SparseTensor(torch.randn(n, cin).cuda(), coordinate_map=m)
         film, res = torch.randn(n, 2 * cout).cuda(), torch.randn(n, cout).cuda()
