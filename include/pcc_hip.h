@@ -233,6 +233,16 @@ int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t*
                     const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                     int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
 
+/* Thin inputs, wide outputs (cin <= 8, cout % 32 == 0: the first layers of the q-map heads and of g_a) on the matrix cores:
+ * out[j, :] = the K * cin inputs of output row j's neighbourhood (zeros for absent neighbours), zero-padded to k2 (a multiple
+ * of 32) columns, stored in the order pcc_conv_fwd's MFMA loop contracts channels — physical column 8 g + s holds logical
+ * column 8 g + 2 (s & 3) + (s >> 2), logical = k * cin + ci.  Followed by a kernel_size-1 pcc_conv_fwd over `out` with the
+ * weights re-laid-out the same way ([1, k2, cout]: row 8 g + [0,4,1,5,2,6,3,7][t] = W[k, ci, :] of logical 8 g + t), the sum
+ * per output element runs over (k, ci) ascending like the scalar thin kernel's: identical bits, the fp32 MFMA being the
+ * same fused multiply-add chain as v_fma_f32. */
+int pcc_im2col_thin(const float* fin, int32_t cin, const int32_t* nbr, int64_t n_out, int32_t K, float* out, int32_t k2,
+                    void* stream);
+
 /* Narrow-head convolution, second half (cout <= 4 on wide inputs: the occupancy logit of
  * model/blocks.py:94-98,142 and the q-map heads).  The caller first computes
  * scores[i, k*cout + c] = in[i] . W[k][:, c] for every INPUT row with one kernel_size-1 call of

@@ -56,6 +56,7 @@ SIGNATURES = {
     "pcc_cast_colsum_scratch_elems": (c_i64, [c_i32]),
     "pcc_cast_colsum": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_epilogue_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_im2col_thin": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_i32, c_void_p, c_i32, c_void_p]),
     "pcc_gather_sum_fwd": (c_int, [c_void_p, c_i32, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_i64, c_i32, c_void_p]),
     "pcc_gather_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_i32, c_void_p]),
     "pcc_scatter_rows": (c_int, [c_void_p, c_i32, c_void_p, c_i64, c_void_p, c_void_p]),

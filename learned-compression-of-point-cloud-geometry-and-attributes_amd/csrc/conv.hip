@@ -932,103 +932,44 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// thin inputs, WIDE outputs (cin <= 16, cout = 32 .. 128 in steps of 32: 2 -> 128 and 4 -> 64, the first layers of the q-map
-// heads and of g_a).  conv_thin_kernel gives a thread 8 output channels of one row, so the 16 threads of a 128-wide row each
-// load the row's 27 indices and 54 inputs and fetch every weight from LDS once per 4 multiply-adds: 0.27-0.45 ms for
-// layers that write 136-218 MB (0.5-1 TB/s; round-3 profiles).  Here a LANE is an output row: its indices and inputs are
-// loaded once, its NCB x 32 accumulators stay in registers, and a weight is one BROADCAST LDS read for 64 rows (every lane
-// reads the same address: conflict-free, 16 bytes per access) — 54 x NCB x 8 reads per 64 rows instead of 16 x 108 per row.
-// Per output element the fused multiply-adds run in conv_thin_kernel's order (k ascending, ci ascending); an absent
-// neighbour contributes fma(0, w, acc) = acc instead of being skipped, which is the same bits (the accumulator starts at
-// +0 and +0 + -0 = +0).  A row's indices come through LDS with coalesced loads; a block stages the weights once and walks
-// row groups with a grid stride.  (A first version with the weights as scalar operands — s_load + v_pk_fma with an SGPR
-// pair — was bound by the scalar loads' latency: 0.17-0.44 ms.)
+// thin inputs, WIDE outputs (cin <= 8, cout a multiple of 32: 2 -> 128 and 4 -> 64, the first layers of the q-map heads and
+// of g_a) as a dense product on the matrix cores.  conv_thin_kernel gives a thread 8 output channels of one row: the 16
+// threads of a 128-wide row each load its 27 indices and 54 inputs and fetch every weight from LDS once per 4
+// multiply-adds — 0.27-0.45 ms for layers that write 136-218 MB (0.5-1 TB/s; round-3 profiles).  But such a layer is a
+// GEMM with a short inner dimension, [rows x K cin] x [K cin x cout], and the fp32 MFMA is the same fused multiply-add chain
+// as v_fma_f32, bit for bit (tools/micro/mfma_shapes_bitwise.hip): im2col_thin_kernel gathers a row's K cin inputs (zeros
+// for absent neighbours, zero padding up to a multiple of 32) into a dense matrix, and the kernel_size-1 instance of
+// conv_mfma_buf_kernel multiplies it with the re-laid-out weights.  The columns are stored in the order the MFMA loop
+// contracts them — within 8 channels it visits 0, 4, 1, 5, 2, 6, 3, 7 — so that per output element the products are added
+// for (k, ci) ascending exactly as conv_thin_kernel adds them (an absent neighbour adds fma(0, w, acc) = acc; the
+// accumulator starts at +0): same bits as the scalar kernel (tests/test_hip_parity.py).
+// (Two scalar-pipe attempts of round 3 — a lane per row with the weights as scalar operands, then as broadcast LDS reads —
+// were bound by scalar-load latency and LDS issue: 0.17-0.57 ms.)
 // ---------------------------------------------------------------------------------------------
-template <int CIN, int NCB>
-__global__ __launch_bounds__(256) void conv_thin_row_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int K = a.K;
-    constexpr int COUT = 32 * NCB;
-    float* wsm = smem;                                                 // [K][CIN][COUT]
-    int32_t* idx_all = reinterpret_cast<int32_t*>(smem + ((K * CIN * COUT + 3) & ~3));
-    int32_t* mine = idx_all + wid * 64 * 27;
-    for (int e = threadIdx.x; e < K * CIN * COUT; e += 256) wsm[e] = a.w[e];
-    __syncthreads();
-    const int64_t groups = (a.n_out + 63) / 64;
-    for (int64_t group = (int64_t)blockIdx.x * 4 + wid; group < groups; group += (int64_t)gridDim.x * 4) {
-        const int64_t row0 = group * 64;
-        const int rows = (int)((a.n_out - row0 < 64) ? (a.n_out - row0) : 64);
-        // the group's 64 x K indices: contiguous in the table, staged with 16-byte loads where aligned
-        {
-            const int32_t* src = a.nbr + row0 * K;
-            const int words = rows * K;
-            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-                for (int w = 4 * lane; w < words; w += 256) {
-                    if (w + 4 <= words) *reinterpret_cast<int4*>(mine + w) = *reinterpret_cast<const int4*>(src + w);
-                    else for (int u = w; u < words; ++u) mine[u] = src[u];
-                }
-            } else {
-                for (int w = lane; w < words; w += 64) mine[w] = src[w];
+__global__ __launch_bounds__(256) void im2col_thin_kernel(const float* __restrict__ fin, int cin, const int32_t* __restrict__ nbr,
+                                                          int64_t n_out, int K, float* __restrict__ out, int k2) {
+    const int q = k2 >> 2;                                   // float4 pieces per row
+    const int64_t total = n_out * q;
+    const int kc = K * cin;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / q;
+        const int c0 = (int)(e - row * q) * 4;               // physical columns c0 .. c0 + 3
+        f32x4 v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = c0 + s;
+            // physical column 8 g + s8 holds the logical column the MFMA loop visits at position inv[s8] of the group
+            const int s8 = c & 7;
+            const int logical = (c & ~7) + ((s8 & 3) << 1 | (s8 >> 2));
+            float x = 0.0f;
+            if (logical < kc) {
+                const int k = logical / cin, ci = logical - k * cin;
+                const int idx = nbr[row * K + k];
+                if (idx >= 0) x = fin[(int64_t)idx * cin + ci];
             }
+            v[s] = x;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const bool live = lane < rows;
-        const int64_t row = row0 + (live ? lane : 0);
-        float acc[NCB][32];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int j = 0; j < 32; ++j) acc[cb][j] = 0.0f;
-        for (int k0 = 0; k0 < K; k0 += 9) {
-            float in[9][CIN];
-#pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                const int idx = (k0 + u < K && live) ? mine[lane * K + k0 + u] : -1;
-                const float* src = a.fin + (int64_t)(idx >= 0 ? idx : 0) * CIN;   // row 0 exists; its values are zeroed below
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) in[u][ci] = idx >= 0 ? src[ci] : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 9; ++u) {
-                if (k0 + u >= K) break;                                           // wave-uniform
-#pragma unroll
-                for (int ci = 0; ci < CIN; ++ci) {
-                    const float* wk = wsm + ((k0 + u) * CIN + ci) * COUT;         // the same address in every lane: broadcast reads
-#pragma unroll
-                    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                        for (int j4 = 0; j4 < 8; ++j4) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wk + cb * 32 + 4 * j4);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[cb][4 * j4 + e] = fmaf(in[u][ci], w4[e], acc[cb][4 * j4 + e]);
-                        }
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();                                          // every lane has read its indices before the next group's land
-        if (!live) continue;
-        float* o = a.fout + row * COUT;
-        const float* fr = a.film ? a.film + row * (2 * (int64_t)COUT) : nullptr;
-        const float* rs = a.residual ? a.residual + row * COUT : nullptr;
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int j4 = 0; j4 < 8; ++j4) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int j = cb * 32 + 4 * j4 + e;
-                    float t = acc[cb][4 * j4 + e] + (a.bias ? a.bias[j] : 0.0f);
-                    if (fr) t = t * fr[j] + fr[COUT + j];
-                    t = apply_act(t, a.act);
-                    if (rs) t += rs[j];
-                    v[e] = t;
-                }
-                *reinterpret_cast<f32x4*>(o + cb * 32 + 4 * j4) = v;
-            }
+        *reinterpret_cast<f32x4*>(out + row * k2 + c0) = v;
     }
 }
 
@@ -1216,31 +1157,6 @@ static int launch_mfma_x3(const ConvArgs& a, hipStream_t st) {
 
 template <int CIN>
 static int launch_thin(const ConvArgs& a, hipStream_t st) {
-    static int row_kernel = -1;       // PCC_THIN_ROW=0: conv_thin_kernel for every shape (A/B; results are bit-identical)
-    if (row_kernel < 0) { const char* e = getenv("PCC_THIN_ROW"); row_kernel = (e && e[0] == '0') ? 0 : 1; }
-    if (row_kernel && a.nbr && a.cout % 32 == 0 && a.cout <= 128 && a.K <= 27 && (reinterpret_cast<uintptr_t>(a.fout) & 15) == 0) {
-        const int64_t groups = (a.n_out + 63) / 64;
-        const size_t lds_row = (size_t)(((a.K * CIN * a.cout + 3) & ~3) + 4 * 64 * 27) * sizeof(float);
-        const unsigned nb = (unsigned)((groups + 3) / 4 < 1024 ? (groups + 3) / 4 : 1024);     // each block stages the weights once
-        auto go = [&](auto kern) {
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_set = true;
-            }
-            hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds_row, st, a);
-        };
-        if (lds_row <= 150 * 1024) {
-            switch (a.cout / 32) {
-                case 1: go(conv_thin_row_kernel<CIN, 1>); break;
-                case 2: go(conv_thin_row_kernel<CIN, 2>); break;
-                case 3: go(conv_thin_row_kernel<CIN, 3>); break;
-                default: go(conv_thin_row_kernel<CIN, 4>); break;
-            }
-            PCC_LAUNCH_CHECK();
-            return PCC_OK;
-        }
-    }
     const size_t lds = (size_t)a.K * CIN * a.cout * sizeof(float);
     PCC_REQUIRE(lds <= 64 * 1024, "conv(thin): weights %zu B exceed LDS budget (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
     // channels per thread: the largest of 8, 4, 2, 1 dividing cout
@@ -1364,6 +1280,18 @@ int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t*
     if (a.coutp % 64 == 0) return tile == 128 ? launch_mfma_x3<128, 64, 2, 2>(a, st) : launch_mfma_x3<64, 64, 2, 2>(a, st);
     pcc::set_error("pcc_conv_fwd_x3: cout=%d not supported (output width rounded up to 32 must be a multiple of 64)", cout);
     return PCC_ERR_UNSUPPORTED;
+}
+
+int pcc_im2col_thin(const float* fin, int32_t cin, const int32_t* nbr, int64_t n_out, int32_t K, float* out, int32_t k2,
+                    void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27 && cin >= 1 && cin <= 16, "pcc_im2col_thin: bad shape (K=%d cin=%d)", K, cin);
+    PCC_REQUIRE(k2 % 32 == 0 && k2 >= K * cin, "pcc_im2col_thin: row length %d must be a multiple of 32 and >= K * cin = %d", k2, K * cin);
+    PCC_REQUIRE(nbr != nullptr && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "pcc_im2col_thin: nbr required, out 16-byte aligned");
+    if (n_out <= 0) return PCC_OK;
+    hipLaunchKernelGGL(im2col_thin_kernel, dim3(blocks_for(n_out * (k2 / 4), 256, 1 << 20)), dim3(256), 0, as_stream(stream), fin, cin, nbr,
+                       n_out, K, out, k2);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
 }
 
 int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int32_t K, int32_t cout, const float* bias,

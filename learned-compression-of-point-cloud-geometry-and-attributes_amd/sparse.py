@@ -478,6 +478,9 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     if (CONV_CO and ksize > 1 and cin % 32 == 0 and cin <= 256 and cout % 64 == 0 and not bf16 and not INFER_X3
             and x_feats.shape[0] * cin * 4 < 0xFFFFF000 and out_map.n * ksize ** 3 * 4 < 0xFFFFE000):
         return _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual)
+    if (THIN_IM2COL and ksize > 1 and cin in (1, 2, 4, 8) and cout % 32 == 0 and ksize ** 3 * cin <= 256
+            and out_map.n * ((ksize ** 3 * cin + 31) // 32 * 32) * 4 < 0xFFFFF000):
+        return _thin_im2col_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, film, residual, out_channels)
     if ksize == 1:
         nbr = pairs = None
         K = 1
@@ -539,6 +542,34 @@ def _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, a
     return out
 
 
+_MFMA_VISIT = (0, 4, 1, 5, 2, 6, 3, 7)     # physical position, within 8 channels, of the t-th channel the MFMA loop contracts
+
+
+def _thin_im2col_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, film, residual, out_channels):
+    """cin <= 8, cout % 32 == 0 (2 -> 128, 4 -> 64: first layers of the q-map heads and of g_a): the row's K * cin inputs gathered
+    into a dense matrix (pcc_im2col_thin) and one kernel_size-1 MFMA convolution over it — the same per-element sum, in the same
+    order, as the scalar thin kernel (csrc/conv.hip), at the matrix cores' rate"""
+    L = _lib.lib()
+    w2p, bias, k2, cout = layer.im2col_weights(out_channels)
+    nbr, _, pairs = in_map.kernel_map(out_map, ksize, transposed)
+    n_out, K, cin = out_map.n, ksize ** 3, x_feats.shape[1]
+    dev = x_feats.device
+    x2 = torch.empty((n_out, k2), dtype=torch.float32, device=dev)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    prof = PROFILER
+    if prof is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(L.pcc_im2col_thin(ptr(x_feats), cin, ptr(nbr), n_out, K, ptr(x2), k2, _lib.stream()))
+    check(L.pcc_conv_fwd(ptr(x2), n_out, k2, None, ptr(w2p), ptr(bias), None, None, None, 1, ptr(out), n_out, cout, act, ptr(film),
+                         ptr(residual), _lib.stream()))
+    if prof is not None:
+        ev1.record()
+        prof.append((f"thin_im2col<{cin}>", cin, cout, pairs, n_out, ev0, ev1, None))
+    return out
+
+
 def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels):
     """cout <= 4 on wide inputs (occupancy logit, q-map heads): per-input-row scores by one dense MFMA
     GEMM, then a scalar gather-sum per output row (see csrc/conv.hip, gather_sum_kernel)."""
@@ -562,6 +593,11 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
         ev1.record()
         prof.append((f"narrow_head<{cin}>", cin, cout, pairs, n_out, ev0, ev1, None))
     return out
+
+
+# Thin-input / wide-output convolutions (cin <= 8, cout % 32 == 0) run as im2col + one kernel_size-1 MFMA convolution
+# (_thin_im2col_forward); PCC_THIN_IM2COL=0 takes the scalar conv_thin_kernel instead (A/B runs; results are bit-identical).
+THIN_IM2COL = os.environ.get("PCC_THIN_IM2COL", "1") == "1"
 
 
 # Experimental, off by default: PCC_CONV_T16=1 / set_conv_t16(True) gives the fp32 inference convolutions over kernel maps 16-row MFMA
@@ -740,6 +776,31 @@ class _ConvBase(nn.Module):
         check(L.pcc_conv_pack_weights_x3(ptr(w), K, cin, cout, ptr(wpx), _lib.stream()))
         self._packed["x"] = (key, wpx)
         return wpx
+
+    def im2col_weights(self, out_channels=None):
+        """Kernel re-laid-out for the thin-input / wide-output path: [1, k2, cout] with row 8 g + _MFMA_VISIT[t] = W[k, ci, :] of
+        logical index 8 g + t = k * cin + ci (zero rows up to k2, a multiple of 32), MFMA-packed; bias; k2; cout."""
+        key = ("im2col", self.kernel._version, self.kernel.data_ptr(), out_channels,
+               None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        hit = self._packed.get("i")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        w, _, b = self.weights(out_channels)
+        K, cin, cout = w.shape
+        kc = K * cin
+        k2 = (kc + 31) // 32 * 32
+        logical = torch.zeros((k2, cout), dtype=torch.float32, device=w.device)
+        logical[:kc] = w.reshape(kc, cout)
+        phys = torch.tensor([8 * (j // 8) + _MFMA_VISIT[j % 8] for j in range(k2)], dtype=torch.long, device=w.device)
+        w2 = torch.empty_like(logical)
+        w2[phys] = logical
+        w2 = w2.unsqueeze(0).contiguous()
+        L = _lib.lib()
+        w2p = torch.empty(L.pcc_conv_packed_elems(1, k2, cout), dtype=torch.float32, device=w.device)
+        check(L.pcc_conv_pack_weights(ptr(w2), 1, k2, cout, ptr(w2p), _lib.stream()))
+        res = (w2p, b, k2, cout)
+        self._packed["i"] = (key, res)
+        return res
 
     def narrow_weights(self, out_channels=None):
         """Kernel re-laid-out for the narrow-head path: [1, cin, K*cout] (+ MFMA packing), bias, K, cout."""

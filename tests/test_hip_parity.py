@@ -604,7 +604,7 @@ h = hashlib.sha256()
 for coords in (c, sub, c[:70], c[:1]):
     n = coords.shape[0]
     m = pcc_amd.CoordMap(torch.from_numpy(coords).cuda(), 1)
-    for cin, cout in ((2, 128), (4, 64), (2, 64), (16, 32), (1, 32), (8, 64)):
+    for cin, cout in ((2, 128), (4, 64), (2, 64), (16, 32), (1, 32), (8, 64), (4, 96)):
         layer = pcc_amd.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, bias=True, dimension=3).cuda()
         x = pcc_amd.SparseTensor(torch.randn(n, cin).cuda(), coordinate_map=m)
         film, res = torch.randn(n, 2 * cout).cuda(), torch.randn(n, cout).cuda()
@@ -621,17 +621,18 @@ print("DIGEST", h.hexdigest())
 """
 
 
-def test_thin_row_kernel_equals_thin_kernel_bitwise():
-    """thin inputs, wide outputs (2 -> 128, 4 -> 64, ...): conv_thin_row_kernel (a lane = a row, a wave = 32 output channels,
-    weights as scalar operands; the default) against conv_thin_kernel (PCC_THIN_ROW=0): the same fused multiply-adds in the
-    same order, so the same bits — over dense / sparse / 70-row / one-row sets, every epilogue, strided and transposed maps"""
+def test_thin_im2col_mfma_equals_thin_kernel_bitwise():
+    """thin inputs, wide outputs (2 -> 128, 4 -> 64, ...): im2col + one kernel_size-1 MFMA convolution (the default) against the
+    scalar conv_thin_kernel (PCC_THIN_IM2COL=0): the fp32 MFMA is the same fused multiply-add chain as v_fma_f32 and the matrix
+    columns are laid out in the order the MFMA loop contracts them, so the same bits — over dense / sparse / 70-row / one-row
+    sets, every epilogue, strided and transposed maps"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
     for flag in ("1", "0"):
-        env = dict(os.environ, PCC_THIN_ROW=flag)
+        env = dict(os.environ, PCC_THIN_IM2COL=flag)
         r = subprocess.run([sys.executable, "-c", _THIN_SCRIPT.format(root=root)], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         digests.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])

@@ -15,7 +15,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 //   out32: C + A B by two 32x32x2 MFMAs (k = 0,1 ; k = 2,3), full 32 x 32
 //   out32t: the same through swapped operands (computes the transpose), stored back un-transposed
 //   out16: the top-left 16 x 16 block by ONE 16x16x4 MFMA
-__global__ void probe(const float* A, const float* B, const float* C, float* out32, float* out32t, float* out16) {
+__global__ void probe(const float* A, const float* B, const float* C, float* out32, float* out32t, float* out16, float* outv) {
     const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
     f32x16 acc, acct;
     for (int i = 0; i < 16; ++i) {
@@ -42,21 +42,29 @@ __global__ void probe(const float* A, const float* B, const float* C, float* out
     const float b16 = B[kq * 32 + j];                 // B[k = kq][j]
     c16 = __builtin_amdgcn_mfma_f32_16x16x4f32(a16, b16, c16, 0, 0, 0);
     for (int reg = 0; reg < 4; ++reg) out16[(4 * kq + reg) * 16 + j] = c16[reg];
+    // the same contraction as a chain of scalar fused multiply-adds (v_fma_f32), k ascending: what csrc/conv.hip's thin kernels run
+    for (int e = lane; e < 1024; e += 64) {
+        const int i = e >> 5, jj = e & 31;
+        float acc1 = C[e];
+        for (int k = 0; k < 4; ++k) acc1 = fmaf(A[i * 4 + k], B[k * 32 + jj], acc1);
+        outv[e] = acc1;
+    }
 }
 
 int main() {
     const int trials = 20000;
-    float *A, *B, *C, *o32, *o32t, *o16;
+    float *A, *B, *C, *o32, *o32t, *o16, *ov;
+    hipMallocManaged(&ov, 1024 * 4);
     hipMallocManaged(&A, 128 * 4); hipMallocManaged(&B, 128 * 4); hipMallocManaged(&C, 1024 * 4);
     hipMallocManaged(&o32, 1024 * 4); hipMallocManaged(&o32t, 1024 * 4); hipMallocManaged(&o16, 256 * 4);
     srand(1);
-    long diff16 = 0, difft = 0, total16 = 0, totalt = 0;
+    long diff16 = 0, difft = 0, total16 = 0, totalt = 0, diffv = 0;
     for (int t = 0; t < trials; ++t) {
         // magnitudes spread over many binades so that every product / partial sum rounds
         auto rnd = [&](int spread) { return (float)((rand() / (double)RAND_MAX - 0.5) * ldexp(1.0, rand() % spread - spread / 2)); };
         for (int i = 0; i < 128; ++i) { A[i] = rnd(12); B[i] = rnd(12); }
         for (int i = 0; i < 1024; ++i) C[i] = (t & 1) ? rnd(20) : 0.0f;
-        hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, A, B, C, o32, o32t, o16);
+        hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, A, B, C, o32, o32t, o16, ov);
         hipDeviceSynchronize();
         for (int i = 0; i < 16; ++i)
             for (int j = 0; j < 16; ++j) {
@@ -70,9 +78,12 @@ int main() {
             uint32_t x, y;
             __builtin_memcpy(&x, &o32[i], 4); __builtin_memcpy(&y, &o32t[i], 4);
             difft += x != y;
+            __builtin_memcpy(&y, &ov[i], 4);
+            diffv += x != y;
         }
     }
     printf("16x16x4 vs two 32x32x2 (k = 0..3): %ld of %ld elements differ bitwise\n", diff16, total16);
     printf("32x32x2 with swapped operands (transposed product): %ld of %ld elements differ bitwise\n", difft, totalt);
+    printf("two 32x32x2 MFMAs vs a chain of four v_fma_f32 (k ascending): %ld of %ld elements differ bitwise\n", diffv, totalt);
     return 0;
 }
