@@ -79,3 +79,23 @@ def test_partition_helpers(pcc):
     assert sorted(sum(parts, [])) == list(range(len(rows)))
     loads = [sum(counts[b] for b in p) for p in parts]
     assert max(loads) - min(loads) <= max(counts)
+
+
+def test_block_partition_at_eight_ranks(pcc):
+    """BASELINE config 4 / north_star's whole-frame mode at its stated width: the cubes of one frame over 8 ranks — every cube
+    to exactly one rank, loads balanced to within one cube, deterministic; with the bench's 512^3 cubes of a 1024^3 frame
+    every rank gets exactly one cube, and a world larger than the cube count leaves ranks empty without failing"""
+    from pcc_amd import parallel as par
+    pts = pcc.synthetic.sphere_shell(128, 54.0, 0.5)                     # a small stand-in with the same topology
+    for block, world in ((64, 8), (32, 8), (64, 16)):
+        ids, rows = par.split_blocks(pts, block)
+        counts = [len(r) for r in rows]
+        parts = par.assign_blocks(counts, world)
+        assert len(parts) == world and sorted(sum(parts, [])) == list(range(len(rows)))
+        assert parts == par.assign_blocks(counts, world)
+        loads = [sum(counts[b] for b in p) for p in parts]
+        assert max(loads) - min(l for l in loads if l or len(rows) >= world) <= max(counts)
+        if block == 64 and world == 8:
+            assert len(rows) == 8 and all(len(p) == 1 for p in parts)      # 2 x 2 x 2 cubes: one per rank
+        if world > len(rows):
+            assert sum(1 for p in parts if not p) == world - len(rows)
