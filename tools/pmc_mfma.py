@@ -36,7 +36,7 @@ def load(name):
 
 
 def template(name):
-    m = re.search(r"(conv_[a-z_0-9]+<[^>]*>)", name)
+    m = re.search(r"(conv_[a-z_0-9]+<[^>]*>)", name) or re.search(r"(conv_[a-z_0-9]+)\(", name)
     return m.group(1).replace(" ", "") if m else None
 
 
@@ -54,9 +54,15 @@ def per_template(name, min_ms=0.0):
             a[k] = a.get(k, 0.0) + x
     return agg
 
+def maybe(name):
+    try:
+        return per_template(name)
+    except AssertionError:
+        return {}
+
 busy = per_template("MFMA_BUSY")
-ops = per_template("MFMA_OPS")
-wave = per_template("WAVE")
+ops = maybe("MFMA_OPS")
+wave = maybe("WAVE")
 top = sorted(busy, key=lambda t: -busy[t]["seconds"])[:6]
 res = {}
 for t in top:
