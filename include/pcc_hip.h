@@ -171,6 +171,13 @@ int pcc_conv_fwd16(const float* fin, int64_t n_in, int32_t cin, const float* w, 
                    const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, const uint32_t* group_mask16, int32_t K,
                    float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
 
+/* Small launches of pcc_conv_fwd / pcc_conv_fwd16 (map convolutions, cin % 32 == 0, whose 32 x 32 output tiles number at most
+ * `workgroups`, twice that for outputs narrower than 128 columns) run on conv_small_kernel: one 16 x 16 MFMA block per wave,
+ * loader waves running the LDS-DMAs ahead — the time of such a launch is one workgroup's serial MFMA chain, which this makes
+ * four times shorter (128 -> 128 on 1,136 rows: 27 us against 66).  Results are bit-identical.  Sets the threshold (default
+ * 640, or PCC_CONV_SMALL_MAX; 0 = never) and returns the previous one; a negative argument only reads it. */
+int64_t pcc_conv_small_max(int64_t workgroups);
+
 /* Convolution in the map's own row order with compacted offset lists (csrc/conv_co.hip) — the default of the fp32
  * inference path for kernel maps (cin % 32 == 0, cout % 64 == 0).  pcc_compact_map turns a kernel map nbr [n_out, K] into,
  * per group of PCC_COMPACT_GROUP consecutive output rows and per offset k, the list of the group's rows that have a

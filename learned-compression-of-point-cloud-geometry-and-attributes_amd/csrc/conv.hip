@@ -873,6 +873,236 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Small launches (a few thousand rows and fewer: the coarse levels of every frame, every level of a small frame).
+// With fewer workgroups than CUs the time of a launch is the time of ONE workgroup, and in the kernels above that is the
+// serial chain of one wave's MFMAs: a 32 x 32 tile over K x cin contraction steps of v_mfma_f32_32x32x2_f32 (64 cycles per
+// two channels) = 46 us for 27 x 128 channels at the peak clock, whatever the row count (measured: 66 us).  Here
+//   * a wave owns ONE 16 x 16 block (v_mfma_f32_16x16x4_f32: 32 cycles per four channels, issued back to back on one
+//     accumulator — tools/micro/mfma_chain_latency.hip — and the same fused multiply-add chain bit for bit, see M16 above),
+//     a workgroup 32 rows x 32 columns: four times the workgroups, every chain a quarter as long (12 us);
+//   * nothing but the chain runs in the MFMA waves' instruction stream.  The fp32 MFMA shares its SIMD with the vector ALU
+//     (any vector instruction between two MFMAs costs its issue time plus ~14 cycles, unhidden) and an LDS-DMA costs its
+//     issuing wave 60-180 cycles: so four LOADER waves (one per SIMD, beside the MFMA wave) issue every DMA of the tile,
+//     NS steps ahead in NS LDS stages, and keep the cursor over the tile's live offsets; an MFMA wave reads the next step's
+//     operands from LDS between its MFMAs (ds_read_b128 with immediate offsets: no address arithmetic) and does its only
+//     vector work — picking two floats of each 16-byte chunk, five LDS bases — in one burst per step;
+//   * the neighbour indices of the tile's 32 rows are staged in LDS once, so every memory operation of a loader's loop is
+//     an LDS-DMA and its counted s_waitcnt is exact; one bare s_barrier per step joins the two roles.
+// A step = SC chunks of 32 channels of one live offset.  Same packed weights, same A-image swizzle, same accumulation
+// order (offsets ascending, channels in MFMA order) and same epilogue as conv_mfma_buf_kernel: results are bit-identical
+// (tests/test_conv_small.py).  In-kernel anatomy at 128 -> 128, 1,136 rows (s_memtime stamps): index staging 0.6 us,
+// first operands 1.1, loop 23.5 (27 steps of 1,917 cycles: 1,024 of MFMA chain, ~290 picking, the rest LDS waits and the
+// barrier), epilogue 1.0.
+// ---------------------------------------------------------------------------------------------
+template <int SC, int NS>
+constexpr int conv_small_lds_bytes() { return (NS * SC * (32 * 32 + 8 * 32 * 4) + 32 * 32) * (int)sizeof(float); }
+
+template <int SC, int NS>
+__global__ __launch_bounds__(512) void conv_small_kernel(const ConvArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int A_STAGE = SC * 32 * 32;          // floats: SC images of 32 rows x 32 channels (128-B rows, swizzled slots)
+    constexpr int W_STAGE = SC * 8 * 32 * 4;       // floats: SC slabs of 8 channel groups x 32 columns x 4
+    constexpr int STAGE = A_STAGE + W_STAGE;
+    constexpr int DMAS = 2 * SC;                   // LDS-DMA instructions per loader thread and step
+    static_assert(NS >= 2 && (NS - 1) * DMAS <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* idx_s = reinterpret_cast<int*>(smem + NS * STAGE);     // [32 rows][K] neighbour indices of my tile (-1 = absent)
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(t >> 6);  // 0-3: MFMA waves, 4-7: loader waves (one of each per SIMD)
+    const int K = a.K;
+    const int ntiles_n = a.coutp / 32;
+    const int64_t tile = blockIdx.x / ntiles_n;
+    const int nt = blockIdx.x - (int)(tile * ntiles_n);
+    const int64_t row0 = tile * 32;
+    uint32_t tmask = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
+    if (a.gmask) tmask &= a.gmask[row0 >> 5];
+    tmask = __builtin_amdgcn_readfirstlane(tmask);
+    const int CG = (a.cin / 32) / SC;                            // steps per offset
+    const int total = __builtin_popcount(tmask) * CG;
+    constexpr int WAIT_FIRST = (NS - 1) * DMAS, WAIT_LOOP = (NS - 2) * DMAS;
+
+    if (tmask != 0u) {
+        for (int e = t; e < 32 * K; e += 512) {
+            const int64_t pos = row0 + e / K;
+            idx_s[e] = pos < a.n_out ? a.nbr[row0 * K + e] : -1;
+        }
+        __syncthreads();
+    }
+    // Barrier B_s, s = 0 .. total: step s has landed in LDS (every loader wave has waited for its share) and the MFMA waves
+    // have their operands of step s - 1 out of LDS.  Both roles pass total + 1 of them.
+    if (wave_u >= 4) {
+        if (tmask == 0u) return;
+        // ---- loader waves: issue every LDS-DMA of the tile (an LDS-DMA costs its wave 60-180 cycles of issue: in an MFMA
+        // wave's stream that is time off the chain), NS steps ahead ----
+        const int lw = wave_u - 4, tl = t - 256;
+        __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 4), BUF_FLAGS);
+        __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wp), 0, (int)((uint32_t)K * a.cin * a.coutp * 4), BUF_FLAGS);
+        // gather role: one wave-instruction fills 1 KB = 8 consecutive rows of an image; lane -> (row, 16-B slot)
+        const int grow = 8 * lw + (lane >> 3);
+        const uint32_t q16 = (uint32_t)(((tl & 7) ^ ((grow >> 1) & 7)) * 16);
+        const uint32_t w_voff = (uint32_t)(((tl >> 5) * a.coutp + nt * 32 + (tl & 31)) * 16);
+        const uint32_t w_kstride = (uint32_t)(a.cin / 4) * a.coutp * 16;     // bytes per kernel offset
+        const uint32_t w_cstride = 8u * a.coutp * 16;                        // bytes per 32-channel chunk
+        const uint32_t a_row_bytes = (uint32_t)a.cin * 4;
+        // cursor (wave-uniform, in scalar registers: a vector-register offset would put every DMA in a readfirstlane loop).
+        // Past the last step the DMAs are pointed out of range: zeros, no traffic, branch-free.
+        uint32_t rem_i = tmask;
+        int k_i = __builtin_ctz(rem_i), cg_i = 0, issued = 0, st_i = 0;
+        rem_i &= rem_i - 1u;
+        auto issue = [&]() {
+            const bool real = issued < total;
+            const int idxv = idx_s[grow * K + k_i];
+            const uint32_t av = (real && idxv >= 0) ? (uint32_t)idxv * a_row_bytes + q16 : BUF_OOB;
+            const uint32_t wv = real ? w_voff : BUF_OOB;
+            const uint32_t aso = (uint32_t)__builtin_amdgcn_readfirstlane(cg_i * SC * 128);
+            const uint32_t wso = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)k_i * w_kstride + (uint32_t)(cg_i * SC) * w_cstride));
+            float* sb = smem + st_i * STAGE + lw * 256;
+#pragma unroll
+            for (int c = 0; c < SC; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(sb + c * 1024), 16, av, aso + c * 128, 0, 0);
+#pragma unroll
+            for (int c = 0; c < SC; ++c)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (lds_ptr_t)(sb + A_STAGE + c * 1024), 16, wv, wso + (uint32_t)c * w_cstride, 0, 0);
+            st_i = (st_i + 1 == NS) ? 0 : st_i + 1;
+            ++issued;
+            const bool wrap = cg_i + 1 == CG;
+            cg_i = wrap ? 0 : cg_i + 1;
+            const bool adv = wrap && rem_i != 0u;
+            k_i = __builtin_amdgcn_readfirstlane(adv ? __builtin_ctz(rem_i) : k_i);
+            rem_i = __builtin_amdgcn_readfirstlane(adv ? (rem_i & (rem_i - 1u)) : rem_i);
+        };
+#pragma unroll
+        for (int s = 0; s < NS; ++s) issue();
+        __builtin_amdgcn_s_waitcnt((WAIT_FIRST & 15) | (7 << 4) | (15 << 8) | ((WAIT_FIRST >> 4) << 14));
+        __builtin_amdgcn_s_barrier();                                         // B_0
+        for (int s = 0; s < total; ++s) {
+            // steps 0 .. s + NS - 1 are issued; all but the newest NS - 2 have landed = step s + 1 is complete
+            __builtin_amdgcn_s_waitcnt((WAIT_LOOP & 15) | (7 << 4) | (15 << 8) | ((WAIT_LOOP >> 4) << 14));
+            __builtin_amdgcn_s_barrier();                                     // B_(s+1): and step s's stage is free
+            issue();                                                          // step s + NS into it
+        }
+        return;
+    }
+
+    // ---- MFMA waves ----
+    const int wrow = 16 * (wave_u >> 1), wcol = 16 * (wave_u & 1);
+    const int j16 = lane & 15, kq = lane >> 4;
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (tmask != 0u) {
+        // Fragments.  Lane (j16, kq) needs floats (kq >> 1) and (kq >> 1) + 2 of the 16-B chunk 2 kk + (kq & 1) of row
+        // wrow + j16 (A) / of channel group 2 kk + (kq & 1), column wcol + j16 (W): the first feeds the sub-block's first MFMA,
+        // the second its second.  Read as dwords these are 4-way bank conflicts (ds_read_b32 banks by address mod 128 B inside
+        // 32-lane groups: 16 rows x 2 chunks land on 8 banks) and the LDS array, twice over, times the step.  So a lane reads
+        // its whole 16-B chunk (ds_read_b128: groups of 16 lanes, 64 banks — conflict-free on this image, the lanes of the
+        // upper half share the lower half's addresses) and picks its two floats afterwards.
+        // Byte addresses: a per-stage base per pattern (four for A — the slot swizzle is an XOR — and one for W), everything
+        // else in the instructions' immediate offsets.
+        const int R = wrow + j16, sw16 = (R >> 1) & 7;
+        uint32_t a_pat[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a_pat[kk] = (uint32_t)((R * 32 + (((2 * kk + (kq & 1)) ^ sw16) * 4)) * 4);
+        const uint32_t w_pat = (uint32_t)((A_STAGE + ((kq & 1) * 32 + wcol + j16) * 4) * 4);
+        uint32_t a_base[4], w_base;                                          // of the stage read next
+        int st_c = 0;
+        auto bases = [&]() {
+            const uint32_t sb = (uint32_t)(st_c * STAGE * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a_base[kk] = sb + a_pat[kk];
+            w_base = sb + w_pat;
+            st_c = (st_c + 1 == NS) ? 0 : st_c + 1;
+        };
+        f32x4 ra[SC * 4], rb[SC * 4];                                         // the next step's chunks, as read
+        float fa0[SC * 4], fa1[SC * 4], fb0[SC * 4], fb1[SC * 4];             // this step's MFMA operands
+        // (inline assembly: the immediate offset carries the chunk / sub-block displacement, so that no vector add sits
+        // between the MFMAs.  The compiler does not count these reads in lgkmcnt: pick() waits for them explicitly.)
+        auto load_sub = [&](auto qc) {                                        // sub-block q = 4 c + kk
+            constexpr int q = decltype(qc)::value;
+            constexpr int ao = (q >> 2) * 4096, wo = (q >> 2) * 4096 + (q & 3) * 1024;
+            const uint32_t ab = a_base[q & 3], wb = w_base;
+            f32x4 va, vb;
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va) : "v"(ab), "n"(ao));
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb) : "v"(wb), "n"(wo));
+            ra[q] = va; rb[q] = vb;
+        };
+        // lanes 32-63 (kq >> 1 = 1) take floats 1 and 3 of a chunk, lanes 0-31 floats 0 and 2: one v_cndmask_b32 per operand
+        // (written out: from "odd ? v[1] : v[0]" the compiler builds an indexed extract of three selects; volatile: behind the wait)
+        const uint64_t upper = 0xFFFFFFFF00000000ull;
+        auto sel = [&](float lo, float hi) {
+            float r;
+            asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(lo), "v"(hi), "s"(upper));
+            return r;
+        };
+        auto pick = [&]() {
+            __builtin_amdgcn_s_waitcnt(0xC07F);       // lgkmcnt(0) (vmcnt, expcnt untouched)
+            __builtin_amdgcn_sched_barrier(0);        // nothing that reads the chunks moves above the wait
+#pragma unroll
+            for (int q = 0; q < SC * 4; ++q) {
+                fa0[q] = sel(ra[q][0], ra[q][1]); fa1[q] = sel(ra[q][2], ra[q][3]);
+                fb0[q] = sel(rb[q][0], rb[q][1]); fb1[q] = sel(rb[q][2], rb[q][3]);
+            }
+        };
+        auto mfma_sub = [&](int q) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa0[q], fb0[q], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa1[q], fb1[q], acc, 0, 0, 0);
+        };
+        // Step s: its operands are in registers.  The fp32 MFMA shares the SIMD with the vector ALU: a vector instruction
+        // between two MFMAs of the chain costs its own issue time plus ~14 cycles, nothing of it hidden
+        // (tools/micro/mfma_chain_latency.hip); LDS reads and scalar instructions are nearly free there.  So the MFMAs of a
+        // step run as one chain with only those between them — the LDS reads of step s + 1's chunks, two sub-blocks per gap,
+        // behind barrier B_(s+1) — and the vector work (LDS bases, picking the next operands) is one burst at its end.
+        // sched_barrier pins that order.
+        auto step = [&]() {
+            mfma_sub(0);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<1, SC * 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                if constexpr (2 * (q - 1) < SC * 4) load_sub(std::integral_constant<int, 2 * (q - 1)>{});
+                if constexpr (2 * (q - 1) + 1 < SC * 4) load_sub(std::integral_constant<int, 2 * (q - 1) + 1>{});
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_sub(q);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            bases();
+            pick();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+
+        __builtin_amdgcn_s_barrier();                                         // B_0
+        bases();
+        static_for<0, SC * 4>([&](auto qc) { load_sub(qc); });
+        bases();
+        pick();
+        __builtin_amdgcn_sched_barrier(0);
+        for (int s = 0; s < total; ++s) step();
+    }
+
+    // epilogue: register e = D[row 4 (lane >> 4) + e][column lane & 15] of my 16 x 16 block
+    const int col = nt * 32 + wcol + j16;
+    if (col < a.cout) {
+        const float bcol = a.bias ? a.bias[col] : 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int64_t pos = row0 + wrow + 4 * kq + e;
+            if (pos >= a.n_out) continue;
+            const int64_t row = a.order ? a.order[pos] : pos;
+            float v = acc[e] + bcol;
+            if (a.film) {
+                const float* fr = a.film + row * (2 * (int64_t)a.cout);
+                v = v * fr[col] + fr[a.cout + col];
+            }
+            v = apply_act(v, a.act);
+            if (a.residual) v += a.residual[row * a.cout + col];
+            a.fout[row * a.cout + col] = v;
+        }
+    }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
 // thin path: cin <= 16 (q-map branches, input layers).  HBM/latency bound; W lives in LDS.
 // One thread per (row, output channel); the gathered inputs are broadcast across the row's lanes.
 // ---------------------------------------------------------------------------------------------
@@ -1091,10 +1321,65 @@ static bool fits_buffer_path(const ConvArgs& a) {
     return (uint64_t)a.n_in * a.cin * 4 <= lim && (uint64_t)a.n_out * a.K * 4 <= lim && (uint64_t)a.K * a.cin * a.coutp * 4 <= lim;
 }
 
+// PCC_CONV_PATH=global forces the 64-bit-addressed kernel (testing; the >= 4 GiB fallback)
+static int conv_path() {
+    static int path = -1;
+    if (path < 0) { const char* e = getenv("PCC_CONV_PATH"); path = (e && e[0] == 'g') ? 1 : 0; }
+    return path;
+}
+
+template <int SC, int NS>
+static int launch_small_impl(const ConvArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = conv_small_kernel<SC, NS>;
+    const int lds = conv_small_lds_bytes<SC, NS>();
+    if (!attr_set) {
+        PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int64_t blocks = ((a.n_out + 31) / 32) * (a.coutp / 32);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, st, a);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+// The small-launch kernel takes a map convolution of at most PCC_CONV_SMALL_MAX (default 640; 0 = never) 32 x 32 output
+// tiles — twice that for outputs narrower than 128 columns, whose ordinary kernel (128-row tiles) fills the chip later.
+// Measured on MI355X (tools/conv_small_bench.py, one launch): 128 -> 128 on 56 .. 1,136 rows 27 us against 66, 64 -> 64
+// 16.5 against 72, 64 -> 128 17 against 38; even at 616 tiles (4,904 rows x 128 columns: 59 against 66; 19,256 rows x 64
+// columns = 1,204 tiles: 62 against 74), behind from 1,000 tiles on (8,000 rows x 128: 90 against 66).
+// PCC_CONV_SMALL_CFG=<chunks per step><stages> forces one pipeline shape (A/B).
+static int64_t g_small_max = -1;
+static int64_t small_max_value() {
+    if (g_small_max < 0) { const char* e = getenv("PCC_CONV_SMALL_MAX"); g_small_max = e ? atoll(e) : 640; }
+    return g_small_max;
+}
+static bool small_launch(const ConvArgs& a) {
+    const int64_t small_max = small_max_value() * (a.coutp % 128 == 0 ? 1 : 2);
+    return a.nbr && conv_path() == 0 && a.cin % 32 == 0 && a.coutp % 32 == 0 && ((a.n_out + 31) / 32) * (a.coutp / 32) <= small_max;
+}
+
+static int launch_small(const ConvArgs& a, hipStream_t st) {
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("PCC_CONV_SMALL_CFG"); cfg = e ? atoi(e) : 0; }
+    const int cch = a.cin / 32;
+    switch (cfg) {
+        case 18: return launch_small_impl<1, 8>(a, st);
+        case 23: if (cch % 2 == 0) return launch_small_impl<2, 3>(a, st); break;
+        case 24: if (cch % 2 == 0) return launch_small_impl<2, 4>(a, st); break;
+        case 43: if (cch % 4 == 0) return launch_small_impl<4, 3>(a, st); break;
+        default: break;
+    }
+    // a step of four chunks (27 barriers for 128 channels instead of 54) while one workgroup per CU — 100 KB of LDS — holds
+    // the launch; else two chunks per step at 52 KB (three workgroups per CU); odd chunk counts one chunk per step
+    const int64_t wgs = ((a.n_out + 31) / 32) * (a.coutp / 32);
+    if (cch % 4 == 0 && wgs <= 256) return launch_small_impl<4, 3>(a, st);
+    return cch % 2 == 0 ? launch_small_impl<2, 3>(a, st) : launch_small_impl<1, 8>(a, st);
+}
+
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_mfma(const ConvArgs& a, hipStream_t st) {
-    static int path = -1;      // PCC_CONV_PATH=global forces the 64-bit-addressed kernel (testing; the >= 4 GiB fallback)
-    if (path < 0) { const char* e = getenv("PCC_CONV_PATH"); path = (e && e[0] == 'g') ? 1 : 0; }
+    const int path = conv_path();
     // 16-row MFMA tiles (pcc_conv_fwd16: a.gmask16 set): instantiated for the channel counts the codec has, maps only.  Waves
     // that own two 32-row tiles (128-row workgroups) take them up to 64 input channels: with four or six channel chunks of
     // straight-line steps x two tiles x three liveness variants the compiler stops promoting the accumulators to registers
@@ -1316,6 +1601,12 @@ int pcc_gather_sum_fwd(const float* scores, int32_t ld, const int32_t* nbr, int3
     return PCC_OK;
 }
 
+int64_t pcc_conv_small_max(int64_t workgroups) {
+    const int64_t before = small_max_value();
+    if (workgroups >= 0) g_small_max = workgroups;
+    return before;
+}
+
 int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
                  const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                  int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
@@ -1347,6 +1638,8 @@ int pcc_conv_fwd16(const float* fin, int64_t n_in, int32_t cin, const float* w, 
         // forces one height for A/B testing.
         static int bm = -1;
         if (bm < 0) { const char* e = getenv("PCC_CONV_BM"); bm = e ? atoi(e) : 0; }
+        // Launches of a few hundred 32 x 32 tiles: one 16 x 16 MFMA block per wave, deep gather pipeline (conv_small_kernel)
+        if (bm == 0 && small_launch(a) && fits_buffer_path(a)) return launch_small(a, st);
         // Launches that would not fill the chip (256 CUs x 3 workgroups) with 128-wide tiles are split
         // into 64-wide column tiles: twice the workgroups, half the MFMAs per step and workgroup.  The
         // accumulation order of an output element does not depend on the tile shape, so results are

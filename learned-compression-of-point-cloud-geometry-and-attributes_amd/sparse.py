@@ -613,6 +613,12 @@ def set_conv_t16(enabled):
     CONV_T16 = bool(enabled)
 
 
+def set_conv_small_max(workgroups):
+    """Threshold (in 32 x 32 output tiles) below which a map convolution runs on the small-launch kernel (csrc/conv.hip,
+    conv_small_kernel; bit-identical results); 0 = never.  Returns the previous threshold; negative = read only."""
+    return int(_lib.lib().pcc_conv_small_max(int(workgroups)))
+
+
 # Experimental, off by default: PCC_CONV_CO=1 / set_conv_co(True) runs the wide fp32 inference convolutions on compacted
 # offset lists in the map's own row order (csrc/conv_co.hip) instead of the mask-ordered kernel of csrc/conv.hip.  Results
 # are bit-identical (tests/test_conv_co.py); on the config-2 frame the mask-ordered kernel is the faster one on every layer
