@@ -51,7 +51,7 @@ def latest_profile(stem):
 
 # what the dominant kernel's time and traffic depend on: the convolution kernel itself and the code that fixes its
 # execution order and kernel maps (a change there changes the gather traffic: VERDICT r2)
-KERNEL_SOURCES = ("conv.hip", "common.h", "coords.hip", "sort.hip", "sort.h", "select.hip")
+KERNEL_SOURCES = ("conv.hip", "common.h", "coords.hip", "sort.hip", "sort.h", "sort_small.h", "select.hip")
 
 
 def kernel_source_sha256():

@@ -137,6 +137,18 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
                            int32_t* order, int32_t* nbr_sorted, uint32_t* group_mask32,
                            void* scratch, int64_t scratch_bytes, void* stream);
 
+/* pcc_kernel_map + pcc_order_rows_by_mask16 (mask order over the whole map: block_log2 < 0) in ONE launch for maps of at
+ * most pcc_small_map_max() output rows (256; 0 when PCC_SMALL_MAP=0): a single 1024-thread workgroup probes, counts, builds
+ * the keys, sorts and permutes — three launches otherwise (six and a memset above 16,384 rows), each a few microseconds of work
+ * behind its dispatch; from ~300 rows on the probes are too much work for one CU.
+ * Outputs as those two calls write them, bit for bit (nbr [n_out, K], row_mask, order, nbr_sorted, group_mask32,
+ * group_mask16); scratch_bytes from pcc_order_scratch_bytes(n_out). */
+int64_t pcc_small_map_max(void);
+int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals, int64_t in_cap,
+                         int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* row_mask, int32_t* order,
+                         int32_t* nbr_sorted, uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes,
+                         void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Sparse convolution forward (ME.MinkowskiConvolution / *ConvolutionTranspose forward,
  * 100+ instances: model/transforms.py:35-57,168-234; model/blocks.py:17-24,86-97,194-220;

@@ -41,6 +41,9 @@ SIGNATURES = {
     "pcc_conv_fwd": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                              c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_conv_small_max": (c_i64, [c_i64]),
+    "pcc_small_map_max": (c_i64, []),
+    "pcc_small_kernel_map": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_compact_map_groups": (c_i64, [c_i64]),
     "pcc_compact_map": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pcc_conv_fwd_co": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i64,

@@ -11,7 +11,7 @@
 #include <stdlib.h>
 
 #include "common.h"
-#include "sort.h"
+#include "sort_small.h"
 
 namespace pcc {
 
@@ -275,11 +275,211 @@ __global__ __launch_bounds__(256) void order_apply_kernel(const int32_t* __restr
     }
 }
 
+
+// Offset counts, keys and the whole sort of a map of at most RS_SMALL_N (16,384) rows in ONE workgroup: what the ordering of
+// such a map ran as a memset and three launches (mask_bit_counts_kernel, order_keys32_kernel, radix_sort_small_kernel),
+// each a few microseconds of work behind its dispatch.  Same counts, same key, same sort: the same order.
+template <int ROUNDS>
+__global__ __launch_bounds__(RS_SMALL_THREADS) void order_small_kernel(const uint32_t* __restrict__ row_mask, int n, uint32_t* keys_a,
+                                                                      uint32_t* keys_b, int32_t* va, int32_t* vb) {
+    __shared__ unsigned cnt27[27];
+    __shared__ int pos_s[27];
+    const int t = threadIdx.x;
+    if (t < 27) cnt27[t] = 0u;
+    __syncthreads();
+    unsigned mine[27];
+#pragma unroll
+    for (int b = 0; b < 27; ++b) mine[b] = 0u;
+    for (int i = t; i < n; i += RS_SMALL_THREADS) {
+        const uint32_t m = row_mask[i];
+#pragma unroll
+        for (int b = 0; b < 27; ++b) mine[b] += (m >> b) & 1u;
+    }
+#pragma unroll
+    for (int b = 0; b < 27; ++b) {
+        unsigned v = mine[b];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((t & 63) == 0 && v) atomicAdd(&cnt27[b], v);
+    }
+    __syncthreads();
+    order_bit_positions(cnt27, pos_s);
+    for (int i = t; i < n; i += RS_SMALL_THREADS) keys_a[i] = order_key_of(row_mask[i] & 0x7FFFFFFu, pos_s);
+    __syncthreads();
+    radix_sort_small_body<uint32_t, ROUNDS>(keys_a, keys_b, va, vb, 1, n, 0, 27, 4);
+}
+
+// ---- a small kernel map and its execution order in ONE launch -----------------------------------------------------------
+// Up to SMALL_MAP_MAX output rows: one 1024-thread workgroup runs what pcc_kernel_map + pcc_order_rows_by_mask16 run as
+// several launches (probe, row masks, offset counts, keys, the one-workgroup radix sort, permuted table + group masks).
+// At these sizes every one of those launches is a few microseconds of work behind ~5 us of dispatch.  Same outputs bit for
+// bit: the same probe, the same key (rarest offset first), the same stable sort.  Measured (tools/small_map_bench.py, one
+// map, host calls included): 56 rows 22 us against 26 for kernel_map + order_small_kernel + order_apply, 300 rows 36
+// against 36, 512 rows 66 against 46 — and 433 against 77 at 4,096: the probes (27 per row, ~150 vector instructions
+// each) are then ONE CU's work, 360 of the 433 us; hence the 256-row limit.
+constexpr int SMALL_MAP_MAX = 256;
+
+// (kernel size as a template parameter: with a runtime K the index arithmetic of a probe — e / K, k % ks, three modulos by the
+// parent pitch — is ~250 vector instructions, and ONE CU issues all of them: 190 us of a 4,096-row map)
+template <int ROUNDS, int KS>
+__global__ __launch_bounds__(RS_SMALL_THREADS) void small_map_kernel(const int32_t* __restrict__ out_coords, int n,
+                                                                    const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                                                    uint64_t tmask, int tshift, int step, int pitch,
+                                                                    int32_t* nbr, uint32_t* __restrict__ row_mask, int32_t* order,
+                                                                    int32_t* __restrict__ nbr_sorted, uint32_t* __restrict__ group_mask32,
+                                                                    uint32_t* __restrict__ group_mask16, uint32_t* keys_a, uint32_t* keys_b,
+                                                                    int32_t* vals_x) {
+    constexpr int ks = KS, K = KS * KS * KS;
+    __shared__ unsigned rm[SMALL_MAP_MAX];
+    __shared__ unsigned cnt27[27];
+    __shared__ int pos_s[27];
+    const int t = threadIdx.x;
+    const bool pow2 = pitch > 0 && (pitch & (pitch - 1)) == 0;
+    auto off_grid = [&](int v) { return pow2 ? (v & (pitch - 1)) != 0 : (v % pitch) != 0; };
+    for (int i = t; i < n; i += RS_SMALL_THREADS) rm[i] = 0u;
+    if (t < 27) cnt27[t] = 0u;
+    __syncthreads();
+    // probes, (row, offset) pairs offset-fastest like kernel_map_kernel — eight per thread at a time: one workgroup has
+    // 16 waves to hide the table's load latency with, so the loads of a batch are issued together (first slot of every
+    // key, then the values of the hits; a key whose first slot holds another key — rare — takes the full search)
+    const int total = n * K;
+    constexpr int U = 8;
+    for (int e0 = t; e0 < total; e0 += RS_SMALL_THREADS * U) {
+        uint64_t key[U], slot[U], got[U];
+        bool live[U];
+        int lrs[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + j * RS_SMALL_THREADS;
+            const bool valid = e < total;
+            const int lr = valid ? e / K : 0, k = valid ? e - lr * K : 0;
+            int dx, dy, dz;
+            kernel_offset(ks, k, dx, dy, dz);
+            const int4 c = reinterpret_cast<const int4*>(out_coords)[lr];
+            const int x = c.y + dx * step, y = c.z + dy * step, z = c.w + dz * step;
+            const bool on_grid = pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z));
+            key[j] = pack_key(c.x, x, y, z);
+            slot[j] = table_slot0(key[j], tmask, tshift);
+            live[j] = valid && on_grid;
+            lrs[j] = lr;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) got[j] = live[j] ? keys[slot[j]] : KEY_EMPTY;
+        int val[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) val[j] = (live[j] && got[j] == key[j]) ? vals[slot[j]] : -1;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + j * RS_SMALL_THREADS;
+            if (e >= total) continue;
+            int idx = val[j];
+            if (live[j] && got[j] != key[j] && got[j] != KEY_EMPTY) idx = table_find(keys, vals, tmask, tshift, key[j]);
+            nbr[e] = idx;
+            if (idx >= 0) atomicOr(&rm[lrs[j]], 1u << (e - lrs[j] * K));
+        }
+    }
+    __syncthreads();
+    // row masks out; rows per offset
+    unsigned mine[27];
+#pragma unroll
+    for (int b = 0; b < 27; ++b) mine[b] = 0u;
+    for (int i = t; i < n; i += RS_SMALL_THREADS) {
+        const uint32_t m = rm[i];
+        row_mask[i] = m;
+#pragma unroll
+        for (int b = 0; b < 27; ++b) mine[b] += (m >> b) & 1u;
+    }
+#pragma unroll
+    for (int b = 0; b < 27; ++b) {
+        unsigned v = mine[b];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if ((t & 63) == 0 && v) atomicAdd(&cnt27[b], v);
+    }
+    __syncthreads();
+    order_bit_positions(cnt27, pos_s);
+    for (int i = t; i < n; i += RS_SMALL_THREADS) keys_a[i] = order_key_of(rm[i] & 0x7FFFFFFu, pos_s);
+    __syncthreads();
+    // 27 key bits = four 8-bit passes: the sorted values (the rows, from an iota) end in the a-side = `order`
+    radix_sort_small_body<uint32_t, ROUNDS>(keys_a, keys_b, order, vals_x, 1, n, 0, 27, 4);
+    // group masks (positions are consecutive across a wave's lanes) and the permuted table
+    for (int i0 = 0; i0 < n; i0 += RS_SMALL_THREADS) {
+        const int i = i0 + t;
+        uint32_t m = (i < n) ? rm[order[i]] : 0u;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
+        if (i < n && (t & 15) == 0) group_mask16[i >> 4] = m;
+        m |= __shfl_xor(m, 16, 64);
+        if (i < n && (t & 31) == 0) group_mask32[i >> 5] = m;
+    }
+    for (int e0 = t; e0 < total; e0 += RS_SMALL_THREADS * U) {          // batched like the probes: two dependent loads per entry
+        int src[U], v[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + j * RS_SMALL_THREADS;
+            src[j] = (e < total) ? order[e / K] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + j * RS_SMALL_THREADS;
+            v[j] = (e < total) ? nbr[(int64_t)src[j] * K + (e - (e / K) * K)] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = e0 + j * RS_SMALL_THREADS;
+            if (e < total) nbr_sorted[e] = v[j];
+        }
+    }
+}
+
 }  // namespace pcc
 
 using namespace pcc;
 
 extern "C" {
+
+int64_t pcc_small_map_max(void) {
+    static int off = -1;          // PCC_SMALL_MAP=0: always the separate launches (A/B)
+    if (off < 0) { const char* e = getenv("PCC_SMALL_MAP"); off = (e && e[0] == '0') ? 1 : 0; }
+    return off ? 0 : SMALL_MAP_MAX;
+}
+
+int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals, int64_t in_cap,
+                         int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* row_mask, int32_t* order,
+                         int32_t* nbr_sorted, uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes,
+                         void* stream) {
+    PCC_REQUIRE(ksize == 2 || ksize == 3, "pcc_small_kernel_map: kernel size must be 2 or 3");
+    PCC_REQUIRE(sign == 1 || sign == -1, "pcc_small_kernel_map: sign must be +1/-1");
+    PCC_REQUIRE(in_cap > 0 && (in_cap & (in_cap - 1)) == 0, "pcc_small_kernel_map: bad capacity");
+    PCC_REQUIRE(step >= 1, "pcc_small_kernel_map: step must be >= 1");
+    PCC_REQUIRE(n_out >= 0 && n_out <= SMALL_MAP_MAX, "pcc_small_kernel_map: %lld rows exceed %d", (long long)n_out, SMALL_MAP_MAX);
+    PCC_REQUIRE(scratch_bytes >= pcc_sort_scratch_bytes(n_out), "pcc_small_kernel_map: scratch too small");
+    if (n_out <= 0) return PCC_OK;
+    const int in_stride = sign > 0 ? step : 2 * step;
+    const int pitch = sign > 0 ? 0 : 2 * step;
+    char* p = reinterpret_cast<char*>(scratch);
+    uint32_t* keys_a = reinterpret_cast<uint32_t*>(p); p += align256(n_out * 8);
+    uint32_t* keys_b = reinterpret_cast<uint32_t*>(p); p += align256(n_out * 8);
+    int32_t* vals_x = reinterpret_cast<int32_t*>(p);
+    const int rounds = (int)(((n_out + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
+    hipStream_t st = as_stream(stream);
+#define PCC_SMALL_MAP(R, S)                                                                                                          \
+    hipLaunchKernelGGL((small_map_kernel<R, S>), dim3(1), dim3(RS_SMALL_THREADS), 0, st, out_coords, (int)n_out, in_keys, in_vals,    \
+                       (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask, order, nbr_sorted,       \
+                       group_mask32, group_mask16, keys_a, keys_b, vals_x)
+#define PCC_SMALL_MAP_R(S)                                                                                                           \
+    do {                                                                                                                             \
+        if (rounds <= 1) PCC_SMALL_MAP(1, S);                                                                                        \
+        else if (rounds <= 2) PCC_SMALL_MAP(2, S);                                                                                   \
+        else PCC_SMALL_MAP(4, S);                                                                                                    \
+    } while (0)
+    if (ksize == 3) PCC_SMALL_MAP_R(3);
+    else PCC_SMALL_MAP_R(2);
+#undef PCC_SMALL_MAP_R
+#undef PCC_SMALL_MAP
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
 
 int64_t pcc_topk_state_elems(int32_t nbatch) { return (int64_t)nbatch * TK_STRIDE; }
 
@@ -328,13 +528,32 @@ int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, in
     int32_t* vals_x = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
     void* counters = p;
     uint32_t* bit_counts = reinterpret_cast<uint32_t*>(p + radix_sort_counter_bytes(n));       // 27 words in the scratch's 256-byte tail
-    PCC_CHECK_HIP(hipMemsetAsync(bit_counts, 0, 27 * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(mask_bit_counts_kernel, dim3(blocks_for(n, 256 * 16, 512)), dim3(256), 0, st, row_mask, n, bit_counts);
     static int legacy = -1;      // PCC_ORDER_KEY=popcount: round 1's key (27 - popcount) << 27 | mask; =natural: rows stay in
     if (legacy < 0) {            // the map's own (generation) order — experiments on gather locality, never the default
         const char* e = getenv("PCC_ORDER_KEY");
         legacy = (e && e[0] == 'p') ? 1 : (e && e[0] == 'n') ? 2 : 0;
     }
+    static int one_wg = -1;      // PCC_ORDER_SMALL=0: the separate launches for small maps too (A/B)
+    if (one_wg < 0) { const char* e = getenv("PCC_ORDER_SMALL"); one_wg = (e && e[0] == '0') ? 0 : 1; }
+    if (one_wg && legacy == 0 && block_log2 < 0 && n <= RS_SMALL_N) {
+        // counts + keys + sort in one workgroup (27 key bits = four passes: the sorted rows end in the a-side = `order`)
+        const int rounds = (int)(((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
+        uint32_t* ka = reinterpret_cast<uint32_t*>(keys_a);
+        uint32_t* kb = reinterpret_cast<uint32_t*>(keys_b);
+#define PCC_ORDER_SMALL(R) hipLaunchKernelGGL(order_small_kernel<R>, dim3(1), dim3(RS_SMALL_THREADS), 0, st, row_mask, (int)n, ka, kb, order, vals_x)
+        if (rounds <= 1) PCC_ORDER_SMALL(1);
+        else if (rounds <= 2) PCC_ORDER_SMALL(2);
+        else if (rounds <= 4) PCC_ORDER_SMALL(4);
+        else if (rounds <= 8) PCC_ORDER_SMALL(8);
+        else PCC_ORDER_SMALL(16);
+#undef PCC_ORDER_SMALL
+        hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
+                           nbr_sorted, group_mask32, group_mask16);
+        PCC_LAUNCH_CHECK();
+        return PCC_OK;
+    }
+    PCC_CHECK_HIP(hipMemsetAsync(bit_counts, 0, 27 * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(mask_bit_counts_kernel, dim3(blocks_for(n, 256 * 16, 512)), dim3(256), 0, st, row_mask, n, bit_counts);
     if (legacy == 2) {
         hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, n);
         hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,

@@ -54,6 +54,26 @@ def _host_count():
     return hit[0]
 
 
+_SMALL_MAP_MAX = None
+_ORDER_KEY_OVERRIDE = bool(os.environ.get("PCC_ORDER_KEY")) or bool(os.environ.get("PCC_KMAP_VARIANT"))   # A/B switches of the separate launches
+
+
+def _small_map_max():
+    """rows up to which a kernel map and its execution order are built by one launch (0 = never; PCC_SMALL_MAP=0)"""
+    global _SMALL_MAP_MAX
+    if _SMALL_MAP_MAX is None:
+        _SMALL_MAP_MAX = int(_lib.lib().pcc_small_map_max())
+    return _SMALL_MAP_MAX
+
+
+def set_small_map_max(rows):
+    """tests / A-B: cap (or switch off with 0) the one-launch small maps; returns the previous cap"""
+    global _SMALL_MAP_MAX
+    was = _small_map_max()
+    _SMALL_MAP_MAX = min(int(rows), int(_lib.lib().pcc_small_map_max())) if rows else 0
+    return was
+
+
 class CoordinateRangeError(ValueError):
     """a coordinate outside the voxel key's range (|c| <= 32000, 0 <= batch index <= 32766: include/pcc_hip.h)"""
 
@@ -214,6 +234,9 @@ class CoordMap:
         hit = self._cache.get(key)
         if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
             return hit[1:]
+        if (0 < out_map.n <= _small_map_max() and ksize in (2, 3) and ORDER_BLOCK_LOG2 < 0 and not _ORDER_KEY_OVERRIDE
+                and ("kmap", id(out_map), ksize, transposed) not in self._cache):
+            return self._small_ordered_kernel_map(out_map, ksize, transposed, key)
         nbr, row_mask, pairs = self.kernel_map(out_map, ksize, transposed)
         L = _lib.lib()
         n_out, K = nbr.shape
@@ -228,6 +251,30 @@ class CoordMap:
                                          ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch), nbytes,
                                          _lib.stream()))
         self._cache[key] = (None if out_map is self else out_map, nbr_sorted, order, gmask, pairs)
+        self._cache[("gmask16",) + key[1:]] = gmask16
+        return nbr_sorted, order, gmask, pairs
+
+    def _small_ordered_kernel_map(self, out_map, ksize, transposed, key):
+        """kernel_map + ordered_kernel_map of a small map in one launch (csrc/select.hip small_map_kernel); fills both caches"""
+        L = _lib.lib()
+        keys, vals, cap = self.table()
+        n_out, K, dev = out_map.n, ksize ** 3, self.device
+        nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
+        row_mask = torch.empty(n_out, dtype=torch.int32, device=dev)
+        order = torch.empty(n_out, dtype=torch.int32, device=dev)
+        nbr_sorted = torch.empty_like(nbr)
+        gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
+        gmask16 = torch.empty((n_out + 15) // 16, dtype=torch.int32, device=dev)
+        nbytes = L.pcc_order_scratch_bytes(n_out)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        step = self.stride // 2 if transposed else self.stride
+        check(L.pcc_small_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step, -1 if transposed else 1,
+                                     ptr(nbr), ptr(row_mask), ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch),
+                                     nbytes, _lib.stream()))
+        pairs = PairCount(row_mask)
+        keep = None if out_map is self else out_map
+        self._cache[("kmap", id(out_map), ksize, transposed)] = (keep, nbr, row_mask, pairs)
+        self._cache[key] = (keep, nbr_sorted, order, gmask, pairs)
         self._cache[("gmask16",) + key[1:]] = gmask16
         return nbr_sorted, order, gmask, pairs
 
@@ -678,6 +725,7 @@ PROFILER = None
 
 
 CONV_BM32_MAX = int(os.environ.get("PCC_CONV_BM32_MAX", "3000"))      # mirrors csrc/conv.hip's tile switch (launch names only)
+CONV_BM = int(os.environ.get("PCC_CONV_BM", "0") or 0)                 # a forced tile height also switches the small-launch kernel off
 
 
 def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
@@ -686,6 +734,11 @@ def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
         cpt = 8 if cout % 8 == 0 else 4 if cout % 4 == 0 else 2 if cout % 2 == 0 else 1
         return f"conv_thin_kernel<{cin}, {cpt}>"
     coutp = (cout + 31) // 32 * 32
+    wgs_small = ((n_out + 31) // 32) * (coutp // 32)
+    if has_nbr and CONV_BM == 0 and wgs_small <= set_conv_small_max(-1) * (1 if coutp % 128 == 0 else 2):
+        cch = cin // 32                               # (PCC_CONV_SMALL_CFG, an A/B switch, is not mirrored)
+        sc, ns = (4, 3) if cch % 4 == 0 and wgs_small <= 256 else (2, 3) if cch % 2 == 0 else (1, 8)
+        return f"conv_small_kernel<{sc}, {ns}>"
     if coutp % 128 == 0:
         wgs128 = ((n_out + 63) // 64) * (coutp // 128)
         bm, bn = (64, 64) if wgs128 < 768 else (32, 128) if wgs128 < CONV_BM32_MAX else (64, 128)

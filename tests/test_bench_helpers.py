@@ -61,4 +61,4 @@ def test_kernel_source_hash_covers_the_coordinate_side_too():
     """the replayed HBM-traffic figure depends on the execution order (coords.hip / sort.hip / select.hip) as well as on
     the convolution kernel: all of them are in the staleness stamp"""
     import bench
-    assert {"conv.hip", "common.h", "coords.hip", "sort.hip", "select.hip", "sort.h"} <= set(bench.KERNEL_SOURCES)
+    assert {"conv.hip", "common.h", "coords.hip", "sort.hip", "select.hip", "sort.h", "sort_small.h"} <= set(bench.KERNEL_SOURCES)

@@ -1,0 +1,127 @@
+"""A small kernel map and its execution order built by ONE launch (csrc/select.hip small_map_kernel, pcc_small_kernel_map)
+against the separate launches (pcc_kernel_map + pcc_order_rows_by_mask16): every output BIT FOR BIT — neighbour table, row
+masks, order, permuted table, group masks per 32 and per 16 positions — for stride-1, strided and transposed maps, kernel
+sizes 2 and 3, from one row to the 256-row limit (and past it: the one-workgroup ordering of maps up to 16,384 rows against the separate launches); and a frame coded to the same bytes either way."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def dev(a):
+    return torch.as_tensor(a).to(DEV).contiguous()
+
+
+def _coords(pcc, n, seed=0, scale=1):
+    rng = np.random.default_rng(seed)
+    p = pcc.synthetic.sphere_shell(64, 27.0, 0.9)[:, :3]
+    p = p[np.argsort(((p - p[0]) ** 2).sum(axis=1))][:n]
+    c = np.concatenate([np.zeros((p.shape[0], 1)), p * scale], axis=1).astype(np.int32)
+    return c[rng.permutation(c.shape[0])]
+
+
+def _maps(pcc, kind, n, seed):
+    """(input map, output map, kernel size, transposed) as the layers build them"""
+    if kind == "same":
+        m = pcc.CoordMap(dev(_coords(pcc, n, seed)), 1)
+        return m, m, 3, False
+    if kind == "down":
+        m = pcc.CoordMap(dev(_coords(pcc, n, seed)), 1)
+        return m, m.down(), 3, False
+    m = pcc.CoordMap(dev(_coords(pcc, n, seed, scale=2)), 2)
+    ks = int(kind[-1])
+    return m, m.up(ks), ks, True
+
+
+def _both(pcc, kind, n, seed):
+    from pcc_amd import sparse as sp
+    outs = []
+    for cap in (1 << 20, 0):
+        was = sp.set_small_map_max(cap)
+        try:
+            m, o, ks, tr = _maps(pcc, kind, n, seed)
+            nbr_sorted, order, gmask, _ = m.ordered_kernel_map(o, ks, tr)
+            g16 = m.group_mask16(o, ks, tr)
+            nbr, row_mask, pairs = m.kernel_map(o, ks, tr)
+            outs.append([t.cpu().numpy() for t in (nbr, row_mask, order, nbr_sorted, gmask, g16)] + [int(pairs.item())])
+        finally:
+            sp.set_small_map_max(was)
+    return outs
+
+
+@pytest.mark.parametrize("kind", ["same", "down", "up3", "up2"])
+@pytest.mark.parametrize("n", [1, 5, 33, 200, 256])
+def test_one_launch_equals_separate_launches(pcc, kind, n):
+    if kind in ("up3", "up2"):
+        n = min(n, 30 if kind == "up3" else 12)    # the child sets are 8-27 x larger: stay under the limit
+    a, b = _both(pcc, kind, n, seed=n)
+    if a[0].shape[0] > 256:
+        pytest.skip("output set above the one-launch limit")
+    names = ("nbr", "row_mask", "order", "nbr_sorted", "group_mask32", "group_mask16")
+    for name, x, y in zip(names, a, b):
+        assert x.shape == y.shape and np.array_equal(x, y), name
+    assert a[-1] == b[-1]
+
+
+@pytest.mark.parametrize("n", [600, 1136, 4904, 9000])
+def test_one_workgroup_ordering_equals_separate_launches(pcc, n):
+    """maps above the one-launch limit: counts + keys + sort in one workgroup (PCC_ORDER_SMALL=0 in a child process: the
+    separate launches)"""
+    import os, subprocess, sys, hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import pcc_amd as pcc
+p = pcc.synthetic.sphere_shell(64, 27.0, 0.9)[:, :3]
+p = p[np.argsort(((p - p[0]) ** 2).sum(axis=1))][:%d]
+c = np.concatenate([np.zeros((p.shape[0], 1)), p], axis=1).astype(np.int32)
+c = torch.from_numpy(c[np.random.default_rng(3).permutation(c.shape[0])]).to("cuda:0")
+m = pcc.CoordMap(c, 1)
+h = hashlib.sha256()
+for t in m.ordered_kernel_map(m, 3)[:3] + (m.group_mask16(m, 3),):
+    h.update(t.cpu().numpy().tobytes())
+print("digest", h.hexdigest())
+""" % (root, n)
+    digests = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, PCC_ORDER_SMALL=v), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0 and "digest" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(r.stdout.split("digest")[-1].strip())
+    assert digests[0] == digests[1]
+
+
+def test_limit_and_switch(pcc):
+    from pcc_amd import sparse as sp
+    cap = sp._small_map_max()
+    assert cap in (0, 256)
+    was = sp.set_small_map_max(0)
+    assert sp._small_map_max() == 0
+    sp.set_small_map_max(was)
+    assert sp._small_map_max() == was
+
+
+def test_frame_codes_to_the_same_bytes(pcc):
+    from pcc_amd import sparse as sp
+    syn = pcc.synthetic
+    model = syn.make_model(0, DEV)
+    model.update()
+    pts = syn.sphere_shell(**syn.CONFIG1)
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+
+    def run():
+        Q = pcc.SparseTensor(coordinates=dev(qc), features=dev(qf), device=DEV)
+        strings, shape, k, coords = model.compress(dev(pts), Q)
+        return strings, shape, k, model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+
+    was = sp.set_small_map_max(0)
+    try:
+        s0, sh0, k0, r0 = run()
+        sp.set_small_map_max(1 << 20)
+        s1, sh1, k1, r1 = run()
+    finally:
+        sp.set_small_map_max(was)
+    assert s0 == s1 and sh0 == sh1 and k0 == k1 and torch.equal(r0, r1)
