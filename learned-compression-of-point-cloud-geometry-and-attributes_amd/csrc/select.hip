@@ -149,6 +149,68 @@ __global__ __launch_bounds__(256) void topk_write_mask(const float* __restrict__
     mask[i] = m;
 }
 
+// One batch item, at most TK_SMALL_N rows: init, the twelve (histogram, pick) rounds and the mask in ONE workgroup — 26
+// launches otherwise, each a few microseconds of work behind its dispatch (a frame of a few thousand points runs three such
+// selections: 72 of its launches).  The same radix select on the same 96-bit keys, the state kept in LDS: the same mask.
+constexpr int TK_SMALL_N = 32768;
+__global__ __launch_bounds__(1024) void topk_small_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ coords, int n,
+                                                          const int32_t* __restrict__ k, uint8_t* __restrict__ mask,
+                                                          int32_t* __restrict__ state) {
+    __shared__ int32_t st[8];
+    __shared__ int h[256];
+    __shared__ int total_s;
+    const int t = threadIdx.x;
+    if (t < 8) st[t] = 0;
+    __syncthreads();
+    if (t == 0) {
+        const int kk = k[0];
+        st[0] = kk;
+        if (kk <= 0) { st[1] = 1; st[2] = 13; }       // select nothing
+    }
+    __syncthreads();
+    for (int pass = 0; pass < 12; ++pass) {
+        if (st[1]) break;                              // uniform: st is only written between barriers
+        if (t < 256) h[t] = 0;
+        __syncthreads();
+        const bool logit_only = pass < 4;              // a pass over the logit bytes: the tie-break key is not needed
+        for (int i = t; i < n; i += 1024) {
+            const int4 c = logit_only ? make_int4(0, 0, 0, 0) : reinterpret_cast<const int4*>(coords)[i];
+            if (c.x != 0) continue;
+            const Key96 key = make_key(logits[(int64_t)i * ld], c);
+            if (cmp_prefix(key, st, pass) != 0) continue;
+            atomicAdd(&h[(key.w[pass >> 2] >> (8 * (3 - (pass & 3)))) & 0xFFu], 1);
+        }
+        __syncthreads();
+        // topk_pick on the LDS state: every thread reads before anyone writes
+        const int krem = st[0];
+        int above = 0, mine = 0;
+        if (t < 256) {
+            mine = h[t];
+            for (int j = t + 1; j < 256; ++j) above += h[j];
+            if (t == 0) total_s = above + mine;
+        }
+        __syncthreads();
+        if (pass == 0 && total_s <= krem) {
+            if (t == 0) { st[1] = 1; st[2] = 0; }      // no more than k rows: keep them all
+        } else if (t < 256 && above < krem && krem <= above + mine) {
+            const int word = pass >> 2, shift = 8 * (3 - (pass & 3));
+            st[3 + word] = (int32_t)((uint32_t)st[3 + word] | ((uint32_t)t << shift));
+            const int knew = krem - above;
+            st[0] = knew;
+            if (mine == knew || pass == 11) { st[1] = 1; st[2] = pass + 1; }
+        }
+        __syncthreads();
+    }
+    const int nb = st[2];
+    for (int i = t; i < n; i += 1024) {
+        const int4 c = reinterpret_cast<const int4*>(coords)[i];
+        uint8_t m = 0;
+        if (c.x == 0 && nb <= 12) m = cmp_prefix(make_key(logits[(int64_t)i * ld], c), st, nb) >= 0 ? 1 : 0;
+        mask[i] = m;
+    }
+    for (int i = t; i < TK_STRIDE; i += 1024) state[i] = i < 8 ? st[i] : 0;      // as the separate launches leave it
+}
+
 __global__ __launch_bounds__(256) void coords_to_keys(const int32_t* __restrict__ coords, int64_t n,
                                                       uint64_t* __restrict__ keys) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -488,6 +550,13 @@ int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_
     PCC_REQUIRE(nbatch >= 1 && nbatch < 32767, "pcc_topk_mask: bad nbatch %d", nbatch);
     PCC_REQUIRE(ld >= 1, "pcc_topk_mask: bad leading dimension");
     hipStream_t st = as_stream(stream);
+    static int one_wg = -1;      // PCC_TOPK_SMALL=0: the separate launches for small selections too (A/B)
+    if (one_wg < 0) { const char* e = getenv("PCC_TOPK_SMALL"); one_wg = (e && e[0] == '0') ? 0 : 1; }
+    if (one_wg && nbatch == 1 && n > 0 && n <= TK_SMALL_N) {
+        hipLaunchKernelGGL(topk_small_kernel, dim3(1), dim3(1024), 0, st, logits, ld, coords, (int)n, k, mask, state);
+        PCC_LAUNCH_CHECK();
+        return PCC_OK;
+    }
     hipLaunchKernelGGL(topk_init, dim3(nbatch), dim3(256), 0, st, k, nbatch, state);
     if (n > 0) {
         const unsigned nb = blocks_for(n, 256, 2048);

@@ -94,6 +94,40 @@ print("digest", h.hexdigest())
     assert digests[0] == digests[1]
 
 
+@pytest.mark.parametrize("n", [1, 700, 20000, 32768])
+def test_one_workgroup_topk_equals_separate_launches(pcc, n):
+    """pcc_topk_mask for one batch item and at most 32,768 rows runs in one workgroup (csrc/select.hip topk_small_kernel);
+    PCC_TOPK_SMALL=0 in a child process = the 26 separate launches.  Ties (equal logits, -0.0), k = 0, 1, n/3, n, n + 5."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import pcc_amd as pcc
+from pcc_amd import sparse as sp
+n = %d
+rng = np.random.default_rng(n)
+flat = rng.choice(64 ** 3, size=n, replace=False)
+c = np.stack([np.zeros(n, np.int64), flat // 4096 - 20, (flat // 64) %% 64 - 3, flat %% 64], axis=1).astype(np.int32)
+logits = rng.normal(size=(n, 3)).astype(np.float32)
+logits[rng.integers(0, n, n // 3 + 1), 0] = 0.25
+logits[rng.integers(0, n, n // 20 + 1), 0] = -0.0
+h = hashlib.sha256()
+for k in (0, 1, n // 3, n, n + 5):
+    m = sp.topk_mask(torch.from_numpy(logits).to("cuda:0"), torch.from_numpy(c).to("cuda:0"), [k], 1).cpu().numpy()
+    assert int(m.sum()) == min(k, n), (k, int(m.sum()))
+    h.update(m.tobytes())
+print("digest", h.hexdigest())
+""" % (root, n)
+    digests = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, PCC_TOPK_SMALL=v), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0 and "digest" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(r.stdout.split("digest")[-1].strip())
+    assert digests[0] == digests[1]
+
+
 def test_limit_and_switch(pcc):
     from pcc_amd import sparse as sp
     cap = sp._small_map_max()
