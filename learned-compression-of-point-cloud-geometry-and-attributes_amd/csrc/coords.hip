@@ -270,6 +270,77 @@ __global__ __launch_bounds__(256) void unique_finalize(Gen gen, int64_t m, int32
     }
 }
 
+// A small candidate set (m <= UNIQUE_SMALL_M) in ONE workgroup: table clear, insert, winner flags, their scan, the output
+// rows and the count — seven launches otherwise, each a few microseconds of work behind its dispatch, on the critical path
+// of a host that waits for the count.  Same rule (the lowest candidate index wins its slot; output rows in candidate
+// order): the same set, the same table.  Winner flags are scanned and finalised 1024 candidates at a time; a finalised slot
+// holds a row id <= its winner's index < any later candidate's index, so a later duplicate still reads "not me".
+constexpr int UNIQUE_SMALL_M = 8192;
+template <class Gen>
+__global__ __launch_bounds__(1024) void unique_small_kernel(Gen gen, int m, uint64_t* keys, int32_t* vals, int64_t cap, int shift,
+                                                            int32_t* __restrict__ slot_of, int32_t* __restrict__ out_coords,
+                                                            int64_t* __restrict__ out_count, int32_t* __restrict__ err) {
+    __shared__ int err_s, carry_s;
+    __shared__ int wsum[16];
+    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
+    const uint64_t mask = (uint64_t)(cap - 1);
+    for (int64_t i = t; i < cap; i += 1024) {
+        keys[i] = KEY_EMPTY;
+        vals[i] = 0x7fffffff;
+    }
+    if (t == 0) { err_s = 0; carry_s = 0; }
+    __syncthreads();
+    for (int i = t; i < m; i += 1024) {
+        int b, x, y, z;
+        gen.get(i, b, x, y, z);
+        if (!coord_in_range(b, x, y, z) || !gen.in_range(i)) {
+            err_s = 1;
+            slot_of[i] = (int32_t)(mask + 1);
+            continue;
+        }
+        const uint64_t slot = table_claim(keys, mask, shift, pack_key(b, x, y, z));
+        slot_of[i] = (int32_t)slot;
+        if (slot <= mask) atomicMin(&vals[slot], (int32_t)i);
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < m; i0 += 1024) {
+        const int i = i0 + t;
+        uint32_t slot = 0;
+        int flag = 0;
+        if (i < m) {
+            slot = (uint32_t)slot_of[i];
+            // (an agent-scope load: the winners were written by atomics at the L2, behind this CU's vector cache, which no
+            // kernel boundary has invalidated in between)
+            flag = (slot <= mask && __hip_atomic_load(&vals[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int32_t)i) ? 1 : 0;
+        }
+        const int inc = wave_inclusive_scan(flag, lane);
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        int base = carry_s, tot = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const int v = wsum[w];
+            if (w < wid) base += v;
+            tot += v;
+        }
+        if (flag) {
+            const int32_t row = base + inc - 1;
+            int b, x, y, z;
+            gen.get(i, b, x, y, z);
+            reinterpret_cast<int4*>(out_coords)[row] = make_int4(b, x, y, z);
+            vals[slot] = row;
+        }
+        __syncthreads();
+        if (t == 0) carry_s += tot;
+        __syncthreads();
+    }
+    if (t == 0) {
+        if (err) *err = err_s;
+        *out_count = err_s ? COUNT_ERR_RANGE : (int64_t)carry_s;
+        __threadfence_system();          // the word may be page-locked host memory that the host polls
+    }
+}
+
 template <class Gen>
 static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int64_t cap, int shift, int32_t* scratch,
                          int32_t* out_coords, int64_t* out_count, hipStream_t st) {
@@ -282,6 +353,14 @@ static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int6
     int32_t* block_sums = scratch + 2 * (m > 0 ? m : 0);
     // the error word lives in the 16 spare ints behind the scan's block sums (pcc_scan_scratch_elems); table_clear zeroes it
     int32_t* err = block_sums + (m > 0 ? (m + SCAN_TILE - 1) / SCAN_TILE : 0) + 8;
+    static int one_wg = -1;      // PCC_UNIQUE_SMALL=0: the separate launches for small sets too (A/B)
+    if (one_wg < 0) { const char* e = getenv("PCC_UNIQUE_SMALL"); one_wg = (e && e[0] == '0') ? 0 : 1; }
+    if (one_wg && m > 0 && m <= UNIQUE_SMALL_M && cap <= 8 * UNIQUE_SMALL_M) {
+        hipLaunchKernelGGL(unique_small_kernel<Gen>, dim3(1), dim3(1024), 0, st, gen, (int)m, keys, vals, cap, shift, slot_of, out_coords,
+                           out_count, err);
+        PCC_LAUNCH_CHECK();
+        return PCC_OK;
+    }
     hipLaunchKernelGGL(table_clear, dim3(blocks_for(cap, 256, 4096)), dim3(256), 0, st, keys, vals, cap, err);
     if (m <= 0) {
         PCC_CHECK_HIP(hipMemsetAsync(out_count, 0, sizeof(int64_t), st));

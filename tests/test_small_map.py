@@ -128,6 +128,45 @@ print("digest", h.hexdigest())
     assert digests[0] == digests[1]
 
 
+@pytest.mark.parametrize("n", [1, 40, 300, 1000, 8000])
+def test_one_workgroup_unique_equals_separate_launches(pcc, n):
+    """coordinate sets of at most 8,192 candidates (strided parents, children of kernel 2 and 3) are built by one workgroup
+    (csrc/coords.hip unique_small_kernel); PCC_UNIQUE_SMALL=0 in a child process = the seven separate launches.  Same rows in
+    the same order, and the same hash table (probed through a kernel map)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+import pcc_amd as pcc
+n = %d
+p = pcc.synthetic.sphere_shell(64, 27.0, 0.9)[:, :3]
+p = p[np.argsort(((p - p[0]) ** 2).sum(axis=1))][:n]
+c = np.concatenate([np.zeros((p.shape[0], 1)), p], axis=1).astype(np.int32)
+c = torch.from_numpy(c[np.random.default_rng(5).permutation(c.shape[0])]).to("cuda:0")
+h = hashlib.sha256()
+m = pcc.CoordMap(c, 1)
+d = m.down()
+h.update(d.coords.cpu().numpy().tobytes())
+h.update(m.kernel_map(d, 3)[0].cpu().numpy().tobytes())
+for ks in (2, 3):
+    if d.n * ks ** 3 > 8192 and n > 300:
+        continue
+    u = d.up(ks)
+    h.update(u.coords.cpu().numpy().tobytes())
+    h.update(d.kernel_map(u, ks, True)[0].cpu().numpy().tobytes())
+    h.update(u.kernel_map(u, 3)[0].cpu().numpy().tobytes())
+print("digest", h.hexdigest())
+""" % (root, n)
+    digests = []
+    for v in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", script], env=dict(os.environ, PCC_UNIQUE_SMALL=v), capture_output=True, text=True,
+                           timeout=300)
+        assert r.returncode == 0 and "digest" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(r.stdout.split("digest")[-1].strip())
+    assert digests[0] == digests[1]
+
+
 def test_limit_and_switch(pcc):
     from pcc_amd import sparse as sp
     cap = sp._small_map_max()
