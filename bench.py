@@ -153,6 +153,7 @@ def parse():
                          "run reports this mode as the `split_bf16` sub-record beside the fp32 value")
     ap.add_argument("--no-x3-record", action="store_true", help="skip the `split_bf16` sub-record of a default run")
     ap.add_argument("--no-streamed-record", action="store_true", help="skip the `streamed` sub-record of a default run")
+    ap.add_argument("--no-small-frame-record", action="store_true", help="skip the `small_frame` sub-record of a default run")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -464,6 +465,57 @@ def main():
                      "note": "opt-in (PCC_INFER_X3=1 / bench.py --x3); the headline `value` is the fp32-multiply run above; encoder "
                              "and decoder must run in the same mode"}
 
+    # ---- a small frame (BASELINE config 1's 4,904-point shell), never `value`: what a frame that cannot fill the chip costs,
+    # with the launches shaped for it (small-launch convolution kernel, one-workgroup map / top-k / coordinate-set chains) and,
+    # in the same process, with all of them switched off — the streams must be the same bytes ----
+    small_frame_record = None
+    if (args.workload == "config2" and not blocks_mode and not args.bf16 and not args.x3 and not args.no_small_frame_record
+            and rank == 0 and world == 1 and not args.file_mode):
+        try:
+            s_pts = syn.sphere_shell(**syn.CONFIG1)
+            s_qc, s_qf = syn.uniform_qmap(s_pts[:, :3], 0.5, 0.5)
+            sx, sqc, sqf = torch.from_numpy(s_pts).to(dev), torch.from_numpy(s_qc).to(dev), torch.from_numpy(s_qf).to(dev)
+
+            def small_steps(n_steps):
+                te = td = 0.0
+                out_ = None
+                for _ in range(n_steps):
+                    torch.cuda.synchronize()
+                    a0 = time.perf_counter()
+                    Qs = pcc_amd.SparseTensor(coordinates=sqc, features=sqf, device=dev)
+                    ss, sshape, sk, sc = model.compress(sx, Qs)
+                    torch.cuda.synchronize()
+                    a1 = time.perf_counter()
+                    srec = model.decompress(coordinates=sc, strings=ss, shape=sshape, k=sk)
+                    torch.cuda.synchronize()
+                    a2 = time.perf_counter()
+                    te += a1 - a0
+                    td += a2 - a1
+                    out_ = (ss, srec)
+                return te / n_steps * 1e3, td / n_steps * 1e3, out_
+
+            def measure():
+                small_steps(8)
+                reps = sorted((small_steps(15) for _ in range(3)), key=lambda r: r[0] + r[1])
+                return reps[1]                                  # the median repetition
+
+            on_e, on_d, on_out = measure()
+            was = (sp.set_conv_small_max(0), sp.set_small_map_max(0), sp.set_small_paths(0))
+            try:
+                off_e, off_d, off_out = measure()
+            finally:
+                sp.set_conv_small_max(was[0]); sp.set_small_map_max(was[1]); sp.set_small_paths(was[2])
+            small_frame_record = {
+                "workload": "config1: 64^3 sphere shell, N=%d points" % s_pts.shape[0], "ms_per_frame": on_e + on_d,
+                "t_enc_ms": on_e, "t_dec_ms": on_d, "value": s_pts.shape[0] / (on_e + on_d) / 1e3, "unit": "Mpoints/s",
+                "small_launch_paths_off": {"ms_per_frame": off_e + off_d, "t_enc_ms": off_e, "t_dec_ms": off_d},
+                "same_bytes_and_points_either_way": bool(on_out[0] == off_out[0] and torch.equal(on_out[1], off_out[1])),
+                "note": "median of three repetitions of 15 frames each; `small_launch_paths_off` = the same process with the "
+                        "small-launch convolution kernel and the one-workgroup chains switched off (pcc_conv_small_max(0), "
+                        "pcc_small_paths(0), no one-launch maps): the tile kernels and separate launches of a full-size frame"}
+        except Exception as e:                                   # a sub-record must not take the headline down with it
+            small_frame_record = {"error": repr(e)}
+
     # ---- third record, never `value`: a streamed sequence — two frames in flight on one GPU (two host threads, each on its
     # own HIP stream), so one frame's serial host range coder runs while the other's kernels do ----
     streamed_record = None
@@ -704,6 +756,8 @@ def main():
         out["split_bf16"] = x3_record
     if streamed_record is not None:
         out["streamed"] = streamed_record
+    if small_frame_record is not None:
+        out["small_frame"] = small_frame_record
     if file_mode is not None:
         out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -144,6 +144,11 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
  * Outputs as those two calls write them, bit for bit (nbr [n_out, K], row_mask, order, nbr_sorted, group_mask32,
  * group_mask16); scratch_bytes from pcc_order_scratch_bytes(n_out). */
 int64_t pcc_small_map_max(void);
+/* One-workgroup forms of the small per-map chains, as a bit mask: 1 = execution order (maps of at most 16,384 rows: counts, keys and
+ * sort in one launch), 2 = top-k (one batch item, at most 32,768 rows), 4 = coordinate sets (at most 8,192 candidates).  All on
+ * by default (PCC_ORDER_SMALL=0 / PCC_TOPK_SMALL=0 / PCC_UNIQUE_SMALL=0 switch one off at start-up); sets the mask and returns
+ * the previous one, a negative argument only reads it.  Outputs do not depend on it. */
+int32_t pcc_small_paths(int32_t mask);
 int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals, int64_t in_cap,
                          int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* row_mask, int32_t* order,
                          int32_t* nbr_sorted, uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes,

@@ -42,6 +42,7 @@ SIGNATURES = {
                              c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_conv_small_max": (c_i64, [c_i64]),
     "pcc_small_map_max": (c_i64, []),
+    "pcc_small_paths": (c_i32, [c_i32]),
     "pcc_small_kernel_map": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_compact_map_groups": (c_i64, [c_i64]),

@@ -127,4 +127,9 @@ __device__ __forceinline__ void kernel_offset(int ks, int k, int& dx, int& dy, i
     dx = ix - c; dy = iy - c; dz = iz - c;
 }
 
+// One-workgroup forms of the small per-map chains (bit 0: execution order <= 16,384 rows, bit 1: top-k <= 32,768 rows, bit 2:
+// coordinate sets <= 8,192 candidates): on unless PCC_ORDER_SMALL=0 / PCC_TOPK_SMALL=0 / PCC_UNIQUE_SMALL=0, or switched at run
+// time through pcc_small_paths (coords.hip; A/B measurements in one process).
+bool small_path_enabled(int bit);
+
 }  // namespace pcc

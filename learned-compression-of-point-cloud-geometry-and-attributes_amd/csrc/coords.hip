@@ -270,6 +270,21 @@ __global__ __launch_bounds__(256) void unique_finalize(Gen gen, int64_t m, int32
     }
 }
 
+static int g_small_paths = -1;
+static int small_paths_value() {
+    if (g_small_paths < 0) {
+        const char* names[3] = {"PCC_ORDER_SMALL", "PCC_TOPK_SMALL", "PCC_UNIQUE_SMALL"};
+        int v = 0;
+        for (int b = 0; b < 3; ++b) {
+            const char* e = getenv(names[b]);
+            if (!(e && e[0] == '0')) v |= 1 << b;
+        }
+        g_small_paths = v;
+    }
+    return g_small_paths;
+}
+bool small_path_enabled(int bit) { return (small_paths_value() >> bit) & 1; }
+
 // A small candidate set (m <= UNIQUE_SMALL_M) in ONE workgroup: table clear, insert, winner flags, their scan, the output
 // rows and the count — seven launches otherwise, each a few microseconds of work behind its dispatch, on the critical path
 // of a host that waits for the count.  Same rule (the lowest candidate index wins its slot; output rows in candidate
@@ -353,9 +368,7 @@ static int unique_coords(Gen gen, int64_t m, uint64_t* keys, int32_t* vals, int6
     int32_t* block_sums = scratch + 2 * (m > 0 ? m : 0);
     // the error word lives in the 16 spare ints behind the scan's block sums (pcc_scan_scratch_elems); table_clear zeroes it
     int32_t* err = block_sums + (m > 0 ? (m + SCAN_TILE - 1) / SCAN_TILE : 0) + 8;
-    static int one_wg = -1;      // PCC_UNIQUE_SMALL=0: the separate launches for small sets too (A/B)
-    if (one_wg < 0) { const char* e = getenv("PCC_UNIQUE_SMALL"); one_wg = (e && e[0] == '0') ? 0 : 1; }
-    if (one_wg && m > 0 && m <= UNIQUE_SMALL_M && cap <= 8 * UNIQUE_SMALL_M) {
+    if (small_path_enabled(2) && m > 0 && m <= UNIQUE_SMALL_M && cap <= 8 * UNIQUE_SMALL_M) {      // PCC_UNIQUE_SMALL=0: never (A/B)
         hipLaunchKernelGGL(unique_small_kernel<Gen>, dim3(1), dim3(1024), 0, st, gen, (int)m, keys, vals, cap, shift, slot_of, out_coords,
                            out_count, err);
         PCC_LAUNCH_CHECK();
@@ -695,6 +708,12 @@ int pcc_children(const int32_t* coords, int64_t n, int32_t ts, int32_t ksize, ui
     const int K = ksize * ksize * ksize;
     GenChildren gen{coords, n, ksize, ts / 2};
     return unique_coords(gen, n * K, keys, vals, cap, grid_shift_of(ts / 2), scratch, out_coords, out_count, as_stream(stream));
+}
+
+int32_t pcc_small_paths(int32_t mask) {
+    const int before = pcc::small_paths_value();
+    if (mask >= 0) pcc::g_small_paths = mask & 7;
+    return before;
 }
 
 int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals,

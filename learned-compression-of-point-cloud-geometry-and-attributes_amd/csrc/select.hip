@@ -550,9 +550,7 @@ int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_
     PCC_REQUIRE(nbatch >= 1 && nbatch < 32767, "pcc_topk_mask: bad nbatch %d", nbatch);
     PCC_REQUIRE(ld >= 1, "pcc_topk_mask: bad leading dimension");
     hipStream_t st = as_stream(stream);
-    static int one_wg = -1;      // PCC_TOPK_SMALL=0: the separate launches for small selections too (A/B)
-    if (one_wg < 0) { const char* e = getenv("PCC_TOPK_SMALL"); one_wg = (e && e[0] == '0') ? 0 : 1; }
-    if (one_wg && nbatch == 1 && n > 0 && n <= TK_SMALL_N) {
+    if (small_path_enabled(1) && nbatch == 1 && n > 0 && n <= TK_SMALL_N) {      // PCC_TOPK_SMALL=0: never (A/B)
         hipLaunchKernelGGL(topk_small_kernel, dim3(1), dim3(1024), 0, st, logits, ld, coords, (int)n, k, mask, state);
         PCC_LAUNCH_CHECK();
         return PCC_OK;
@@ -602,9 +600,7 @@ int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, in
         const char* e = getenv("PCC_ORDER_KEY");
         legacy = (e && e[0] == 'p') ? 1 : (e && e[0] == 'n') ? 2 : 0;
     }
-    static int one_wg = -1;      // PCC_ORDER_SMALL=0: the separate launches for small maps too (A/B)
-    if (one_wg < 0) { const char* e = getenv("PCC_ORDER_SMALL"); one_wg = (e && e[0] == '0') ? 0 : 1; }
-    if (one_wg && legacy == 0 && block_log2 < 0 && n <= RS_SMALL_N) {
+    if (small_path_enabled(0) && legacy == 0 && block_log2 < 0 && n <= RS_SMALL_N) {      // PCC_ORDER_SMALL=0: never (A/B)
         // counts + keys + sort in one workgroup (27 key bits = four passes: the sorted rows end in the a-side = `order`)
         const int rounds = (int)(((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
         uint32_t* ka = reinterpret_cast<uint32_t*>(keys_a);

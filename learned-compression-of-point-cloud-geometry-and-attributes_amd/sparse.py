@@ -74,6 +74,12 @@ def set_small_map_max(rows):
     return was
 
 
+def set_small_paths(mask):
+    """one-workgroup forms of the small per-map chains (bit 0 execution order, 1 top-k, 2 coordinate sets; include/pcc_hip.h):
+    sets the mask, returns the previous one; negative = read only"""
+    return int(_lib.lib().pcc_small_paths(int(mask)))
+
+
 class CoordinateRangeError(ValueError):
     """a coordinate outside the voxel key's range (|c| <= 32000, 0 <= batch index <= 32766: include/pcc_hip.h)"""
 

@@ -49,7 +49,7 @@ def test_parallel_helpers_over_rccl_world_of_one():
 @pytest.mark.parametrize("partition", ["frames", "blocks"])
 def test_bench_multi_gpu_branches_over_rccl_world_of_one(partition):
     r = _run([sys.executable, "bench.py", "--workload", "config1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
-              "--no-x3-record", "--no-streamed-record", "--partition", partition, "--block", "16"],
+              "--no-x3-record", "--no-streamed-record", "--no-small-frame-record", "--partition", partition, "--block", "16"],
              {"PCC_BENCH_FORCE_DIST": "1"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -77,7 +77,7 @@ def test_bench_starts_its_own_two_ranks():
     that has not touched the GPU) and relays rank 0's line.  One GPU here, so the ranks share cuda:0 and the collectives
     run over gloo (PCC_BENCH_REHEARSE=1): the control flow of an N-GPU run, not a measurement."""
     r = _run([sys.executable, "bench.py", "--gpus", "2", "--workload", "config1", "--steps", "2", "--warmup", "1",
-              "--no-cpu-baseline", "--no-x3-record", "--no-streamed-record", "--block", "16"],
+              "--no-cpu-baseline", "--no-x3-record", "--no-streamed-record", "--no-small-frame-record", "--block", "16"],
              {"PCC_BENCH_REHEARSE": "1"}, timeout=400)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])

@@ -167,6 +167,33 @@ print("digest", h.hexdigest())
     assert digests[0] == digests[1]
 
 
+def test_runtime_switch_of_the_one_workgroup_paths(pcc):
+    """pcc_small_paths: the mask reads back, and a frame codes to the same bytes with every path off and on in one process
+    (what bench.py's `small_frame` record does)"""
+    from pcc_amd import sparse as sp
+    was = sp.set_small_paths(-1)
+    assert 0 <= was <= 7
+    assert sp.set_small_paths(5) == was and sp.set_small_paths(-1) == 5 and sp.set_small_paths(was) == 5
+    syn = pcc.synthetic
+    model = syn.make_model(0, DEV)
+    model.update()
+    pts = syn.sphere_shell(**syn.CONFIG1)
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+
+    def run():
+        Q = pcc.SparseTensor(coordinates=dev(qc), features=dev(qf), device=DEV)
+        strings, shape, k, coords = model.compress(dev(pts), Q)
+        return strings, shape, k, model.decompress(coordinates=coords, strings=strings, shape=shape, k=k)
+
+    state = (sp.set_conv_small_max(0), sp.set_small_map_max(0), sp.set_small_paths(0))
+    try:
+        s0, sh0, k0, r0 = run()
+    finally:
+        sp.set_conv_small_max(state[0]); sp.set_small_map_max(state[1]); sp.set_small_paths(state[2])
+    s1, sh1, k1, r1 = run()
+    assert s0 == s1 and sh0 == sh1 and k0 == k1 and torch.equal(r0, r1)
+
+
 def test_limit_and_switch(pcc):
     from pcc_amd import sparse as sp
     cap = sp._small_map_max()
