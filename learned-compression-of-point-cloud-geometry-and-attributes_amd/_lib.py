@@ -138,17 +138,26 @@ def ptr(t):
     """Device (or host) pointer of a tensor / numpy array, or NULL."""
     if t is None:
         return None
-    if hasattr(t, "data_ptr"):
+    try:
         return t.data_ptr()
-    return t.ctypes.data
+    except AttributeError:
+        return t.ctypes.data
+
+
+_raw_stream = None
 
 
 def stream():
     """Raw handle of the calling thread's current HIP stream on the current device.  Asked for at every launch (~230 times
     per frame): torch.cuda.current_stream() builds a Stream object through several Python layers (8.6 us, 2 ms per
     frame); the two C calls below return the same handle in well under a microsecond."""
-    import torch
-    try:
-        return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
-    except AttributeError:                      # a torch build without the private accessors
-        return torch.cuda.current_stream().cuda_stream
+    global _raw_stream
+    if _raw_stream is None:
+        import torch
+        try:
+            get_stream, get_dev = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+            get_stream(get_dev())
+            _raw_stream = lambda: get_stream(get_dev())
+        except AttributeError:                      # a torch build without the private accessors
+            _raw_stream = lambda: torch.cuda.current_stream().cuda_stream
+    return _raw_stream()

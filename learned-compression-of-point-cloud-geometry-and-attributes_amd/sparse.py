@@ -355,6 +355,15 @@ class SparseTensor:
             raise ValueError(f"{features.shape[0]} feature rows for {self.map.n} coordinates")
         self.F = features.contiguous()
 
+    @classmethod
+    def _wrap(cls, feats, coordinate_map):
+        """an operator's own output (fp32, contiguous, on the map's device, one row per coordinate): no checks, no conversions —
+        the constructor's cost is paid a hundred times per frame"""
+        t = object.__new__(cls)
+        t.map = coordinate_map
+        t.F = feats
+        return t
+
     @property
     def C(self):
         return self.map.coords
@@ -910,7 +919,7 @@ class _ConvBase(nn.Module):
             return SparseTensor(feats, coordinate_map=out_map)
         feats = conv_forward(x.F, x.map, out_map, self, self.kernel_size, self.transposed, act, film, residual,
                              out_channels)
-        return SparseTensor(feats, coordinate_map=out_map)
+        return SparseTensor._wrap(feats, out_map)
 
 
 class MinkowskiConvolution(_ConvBase):
