@@ -531,14 +531,14 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     """out = act(film(bias + sum_k in[nbr] @ W[k])) + residual — one fused launch."""
     L = _lib.lib()
     w, wp, bias = layer.weights(out_channels)
-    cin = x_feats.shape[1]
+    n_in, cin = x_feats.shape
     cout = w.shape[-1]
     if ksize > 1 and cin % 32 == 0 and cout <= NARROW_HEAD_MAX_COUT and film is None and residual is None:
         return _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels)
     order = gmask = None
-    bf16 = INFER_BF16 and cin % 64 == 0 and x_feats.shape[0] * cin * 2 < 0xFFFFF000
+    bf16 = INFER_BF16 and cin % 64 == 0 and n_in * cin * 2 < 0xFFFFF000
     if (CONV_CO and ksize > 1 and cin % 32 == 0 and cin <= 256 and cout % 64 == 0 and not bf16 and not INFER_X3
-            and x_feats.shape[0] * cin * 4 < 0xFFFFF000 and out_map.n * ksize ** 3 * 4 < 0xFFFFE000):
+            and n_in * cin * 4 < 0xFFFFF000 and out_map.n * ksize ** 3 * 4 < 0xFFFFE000):
         return _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual)
     if (THIN_IM2COL and ksize > 1 and cin in (1, 2, 4, 8) and cout % 32 == 0 and ksize ** 3 * cin <= 256
             and out_map.n * ((ksize ** 3 * cin + 31) // 32 * 32) * 4 < 0xFFFFF000):
@@ -554,23 +554,31 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         K = ksize ** 3
     n_out = out_map.n
     out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
-    x3 = (INFER_X3 and not bf16 and cin % 32 == 0 and ((cout + 31) // 32 * 32) % 64 == 0 and x_feats.shape[0] * cin * 4 < 0xFFFFF000
+    x3 = (INFER_X3 and not bf16 and cin % 32 == 0 and ((cout + 31) // 32 * 32) % 64 == 0 and n_in * cin * 4 < 0xFFFFF000
           and (nbr is None or n_out * K * 4 < 0xFFFFF000))
     prof = PROFILER
+    if prof is None and not bf16 and not x3 and not CONV_T16:
+        # the default inference launch, without the bookkeeping of the other modes (a hundred of these per small frame)
+        check(L.pcc_conv_fwd16(x_feats.data_ptr(), n_in, cin, w.data_ptr(), None if wp is None else wp.data_ptr(),
+                               None if bias is None else bias.data_ptr(), None if nbr is None else nbr.data_ptr(),
+                               None if order is None else order.data_ptr(), None if gmask is None else gmask.data_ptr(), None, K,
+                               out.data_ptr(), n_out, cout, act, None if film is None else film.data_ptr(),
+                               None if residual is None else residual.data_ptr(), _lib.stream()))
+        return out
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
     if bf16:
         xb = x_feats.to(torch.bfloat16)
-        check(L.pcc_conv_fwd_bf16(ptr(xb), x_feats.shape[0], cin, ptr(layer.weights_bf16(out_channels)), ptr(bias), ptr(nbr),
+        check(L.pcc_conv_fwd_bf16(ptr(xb), n_in, cin, ptr(layer.weights_bf16(out_channels)), ptr(bias), ptr(nbr),
                                   ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     elif x3:
-        check(L.pcc_conv_fwd_x3(ptr(x_feats), x_feats.shape[0], cin, ptr(layer.weights_x3(out_channels)), ptr(bias), ptr(nbr),
+        check(L.pcc_conv_fwd_x3(ptr(x_feats), n_in, cin, ptr(layer.weights_x3(out_channels)), ptr(bias), ptr(nbr),
                                 ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     else:
         g16 = in_map.group_mask16(out_map, ksize, transposed) if (CONV_T16 and gmask is not None) else None
-        check(L.pcc_conv_fwd16(ptr(x_feats), x_feats.shape[0], cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask),
+        check(L.pcc_conv_fwd16(ptr(x_feats), n_in, cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask),
                                ptr(g16), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
         coutp = (cout + 31) // 32 * 32
         two_tiles = coutp % 128 != 0                 # 128 x 64 and 128 x 32 workgroups: two 32-row tiles per wave (csrc/conv.hip)
@@ -798,8 +806,10 @@ class _ConvBase(nn.Module):
     def weights(self, out_channels=None):
         """(raw kernel, MFMA-packed kernel or None, bias or None), optionally sliced to the first
         ``out_channels`` outputs (used where the reference reads only channel 0: blocks.py:142)."""
-        key = (self.kernel._version, self.kernel.data_ptr(), out_channels,
-               None if self.bias is None else (self.bias._version, self.bias.data_ptr()))
+        params = self._parameters                    # (not self.kernel / self.bias: Module.__getattr__ is ~0.7 us a time)
+        kernel, bias_p = params["kernel"], params.get("bias")
+        key = (kernel._version, kernel.data_ptr(), out_channels,
+               None if bias_p is None else (bias_p._version, bias_p.data_ptr()))
         hit = self._packed.get("w")
         if hit is not None and hit[0] == key:
             return hit[1]
