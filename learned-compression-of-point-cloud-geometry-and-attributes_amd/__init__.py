@@ -6,8 +6,17 @@ build contract is not a valid Python identifier).
 Public surface (mirrors /root/reference/model/): ``ColorModel``, ``SparseTensor``, the
 ``Minkowski*`` layer classes, ``EntropyBottleneck`` / ``GaussianConditional``.
 """
-from . import _lib
-from ._lib import build, lib  # noqa: F401
+import os as _os
+
+# A frame in flight uses two HIP streams (its own and the map-prefetch side stream), a streamed sequence two frames: four busy
+# streams beside the default one.  The runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and two
+# streams on one queue run one after the other: when the two frames' main streams landed on the same queue a streamed run
+# took sequential time or more (bench.py's `streamed` record read 82 or 102-114 ms per frame from one process to the next;
+# with 8 queues always 82).  Read by the HIP runtime at its initialisation — set here, before anything touches the GPU.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+from . import _lib  # noqa: E402
+from ._lib import build, lib  # noqa: F401,E402
 from .sparse import (CoordMap, SparseTensor, MinkowskiConvolution, MinkowskiConvolutionTranspose,  # noqa: F401
                      MinkowskiGenerativeConvolutionTranspose, MinkowskiPruning, MinkowskiReLU, MinkowskiLeakyReLU)
 from .entropy import EntropyBottleneck, GaussianConditional  # noqa: F401
