@@ -524,40 +524,62 @@ def main():
             and not args.file_mode):
         import threading
 
-        def run_stream(workers, n_frames):
-            nxt, lock, done, errs = [0], threading.Lock(), [], []
+        import queue
 
-            def worker():
-                try:
-                    s_ = torch.cuda.Stream(device=dev)
-                    with torch.cuda.stream(s_):
-                        while True:
-                            with lock:
-                                i = nxt[0]
-                                nxt[0] += 1
-                            if i >= n_frames:
-                                break
-                            Qs = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)
-                            ss, sshape, sk, sc = model.compress(x, Qs)
-                            srec = model.decompress(coordinates=sc, strings=ss, shape=sshape, k=sk)
-                            done.append((srec.shape[0], pcc_amd.utils.count_bits(ss)))
-                        s_.synchronize()
-                except BaseException as e:               # surfaced below: a worker's failure must fail the bench
-                    errs.append(e)
+        # Two PERSISTENT workers (a streaming coder's shape): each owns a HIP stream and, through its thread id, its pinned
+        # staging buffers, count word and prefetch side stream for the whole record.  (Workers created anew for every
+        # repetition re-created all of that inside the timed span, and the record read 82 or 102-114 ms per frame from one
+        # process to the next.)  Frames are handed out through a queue; the second worker's first frame of a run is held back
+        # by half a sequential frame — frames of a sequence arrive one after the other, and two frames started together can
+        # stay in lock-step: both in their convolutions, then both in their host range coders.
+        stagger_s = 0.5 * (t_enc + t_dec) / max(args.steps, 1)
+        jobs, results, errs = queue.Queue(), queue.Queue(), []
+
+        def worker(wi):
+            try:
+                s_ = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(s_):
+                    while True:
+                        job = jobs.get()
+                        if job is None:
+                            break
+                        if job == "hold":
+                            time.sleep(stagger_s)
+                            continue
+                        Qs = pcc_amd.SparseTensor(coordinates=q_coords, features=q_feats, device=dev)
+                        ss, sshape, sk, sc = model.compress(x, Qs)
+                        srec = model.decompress(coordinates=sc, strings=ss, shape=sshape, k=sk)
+                        results.put((srec.shape[0], pcc_amd.utils.count_bits(ss)))
+            except BaseException as e:               # surfaced below: a worker's failure must fail the bench
+                errs.append(e)
+                results.put(None)
+
+        workers_ = [threading.Thread(target=worker, args=(wi,), daemon=True) for wi in range(2)]
+        [t.start() for t in workers_]
+
+        def run_stream(_workers, n_frames):
             torch.cuda.synchronize()
             ts0 = time.perf_counter()
-            ths = [threading.Thread(target=worker) for _ in range(workers)]
-            [t.start() for t in ths]
-            [t.join() for t in ths]
+            jobs.put("frame")                            # the first worker starts at once,
+            jobs.put("hold")                             # the second takes the hold, then frames like the first
+            for _ in range(n_frames - 1):
+                jobs.put("frame")
+            done = []
+            for _ in range(n_frames):
+                r_ = results.get()
+                if r_ is None or errs:
+                    raise errs[0]
+                done.append(r_)
             torch.cuda.synchronize()
-            if errs:
-                raise errs[0]
             return time.perf_counter() - ts0, done
 
+        _swi = sys.getswitchinterval()
+        if os.environ.get("PCC_STREAM_SWITCH_INTERVAL"):
+            sys.setswitchinterval(float(os.environ["PCC_STREAM_SWITCH_INTERVAL"]))
         try:
             # The two-thread record swings between runs (thread timing against the interpreter lock: the driver's round-2 run
             # and the committed profile disagreed by 25 %): three repetitions, the MEDIAN is the value, min / max beside it
-            s_frames = max(8, min(16, 4 * args.steps))
+            s_frames = max(8, min(32, 4 * args.steps))          # the half-frame stagger is inside the timed span: amortised over the run
             s_reps = 3
             run_stream(2, 4)                                  # per-thread warm-up (pinned staging, side streams, count words)
             runs = [run_stream(2, s_frames) for _ in range(s_reps)]
@@ -588,6 +610,10 @@ def main():
             import traceback
             traceback.print_exc(file=sys.stderr)
             streamed_record = {"error": repr(e)[:300]}
+        finally:
+            sys.setswitchinterval(_swi)
+            [jobs.put(None) for _ in workers_]
+            [t.join(timeout=30) for t in workers_]
 
     # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
     classes = {}
