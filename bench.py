@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 # the pool's host driver shares device memory between processes (RCCL) through dmabuf only
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # see pcc_amd/__init__.py: two frames in flight = four busy streams
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")        # see pcc_amd/__init__.py: two frames in flight = four busy streams beside the default one
 import numpy as np
 import torch
 

@@ -9,10 +9,12 @@ Public surface (mirrors /root/reference/model/): ``ColorModel``, ``SparseTensor`
 import os as _os
 
 # A frame in flight uses two HIP streams (its own and the map-prefetch side stream), a streamed sequence two frames: four busy
-# streams beside the default one.  The runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and two
-# streams on one queue run one after the other: when the two frames' main streams landed on the same queue a streamed run
-# took sequential time or more (bench.py's `streamed` record read 82 or 102-114 ms per frame from one process to the next;
-# with 8 queues always 82).  Read by the HIP runtime at its initialisation — set here, before anything touches the GPU.
+# streams beside the default one, and the runtime spreads streams over GPU_MAX_HW_QUEUES hardware queues (default 4) — two
+# streams on one queue run one after the other.  Eight queues keep the two frames' streams apart whatever order they were
+# created in.  (Looked at while bench.py's `streamed` record read 82 or 102-114 ms per frame from one process to the next;
+# that turned out to be the record re-creating its worker threads — one run with eight queues still hit the bad mode — but
+# four busy streams on four queues shared with the default stream is a collision waiting to happen.)  Read by the HIP
+# runtime at its initialisation: set here, before anything touches the GPU.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from . import _lib  # noqa: E402
