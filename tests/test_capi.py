@@ -41,6 +41,14 @@ def test_host_entry_points_without_gpu(pcc):
     assert L.pcc_scan_scratch_elems(5000) >= 2 * 5000
     assert L.pcc_conv_packed_elems(27, 128, 3) == 27 * 128 * 32
     assert L.pcc_topk_state_elems(2) >= 2 * 259
+    # the thresholds of the small-launch paths are host state: defaults, set / read back, restore
+    assert L.pcc_small_map_max() in (0, 256)
+    was = L.pcc_conv_small_max(-1)
+    assert was == 640 or os.environ.get("PCC_CONV_SMALL_MAX")
+    assert L.pcc_conv_small_max(17) == was and L.pcc_conv_small_max(was) == 17 and L.pcc_conv_small_max(-1) == was
+    paths = L.pcc_small_paths(-1)
+    assert 0 <= paths <= 7
+    assert L.pcc_small_paths(2) == paths and L.pcc_small_paths(paths) == 2 and L.pcc_small_paths(-1) == paths
     # error path: message available, no exception across the ABI
     pmf = np.array([-1.0, 2.0], dtype=np.float32)
     cdf = np.zeros(3, dtype=np.int32)
