@@ -634,7 +634,9 @@ def main():
         return pop_cache[key]
 
     launches = []
-    for name, cin, cout, pairs, n_out, e0, e1, gmask in prof:
+    for entry in prof:
+        name, cin, cout, pairs, n_out, e0, e1, gmask = entry
+        name = sp.profiled_name(entry)
         p = int(pairs.item()) if torch.is_tensor(pairs) else int(pairs)
         c = classes.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, gather_bytes=0.0, exec_flops=0.0))
         ex = 0.0 if name.startswith("narrow") else 2.0 * 32 * active_slots(gmask, n_out) * cin * ((cout + 31) // 32 * 32)

@@ -586,11 +586,19 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
             gmask = g16                              # the profiler's issued-row count follows the tile height
     if prof is not None:
         ev1.record()
-        name = conv_kernel_name(cin, cout, n_out, nbr is not None)
-        tag = "[bf16]" if bf16 else "[x3]" if x3 else ""
-        prof.append((name.replace("conv_mfma_buf_kernel", "conv_mfma_buf_kernel" + tag), cin, cout,
+        # the launch's name is worked out by the reader (profiled_name): string building has no place between two launches
+        prof.append((("conv", "[bf16]" if bf16 else "[x3]" if x3 else "", nbr is not None), cin, cout,
                      pairs if pairs is not None else n_out, n_out, ev0, ev1, gmask))
     return out
+
+
+def profiled_name(entry):
+    """kernel name of a PROFILER entry (conv_forward stores what the name is made from)"""
+    name, cin, cout, _, n_out = entry[:5]
+    if isinstance(name, tuple):
+        _, tag, has_nbr = name
+        return conv_kernel_name(cin, cout, n_out, has_nbr).replace("conv_mfma_buf_kernel", "conv_mfma_buf_kernel" + tag)
+    return name
 
 
 def _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual):
