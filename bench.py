@@ -344,6 +344,8 @@ def main():
         step(False)
 
     sp.PROFILER = []
+    if args.breakdown:
+        sp.PROFILER_MIN_ROWS = 0                  # the per-launch table wants every launch's time
     # The interpreter's cyclic collector: a FULL collection walks every container object alive — ~215 k after importing torch and
     # building the model — and takes 80-135 ms in this process; the per-launch records below (events, tuples) age into the old
     # generation and provoke exactly one during the timed steps (always the 9th of 20: 173-237 ms instead of 99; a plain
@@ -659,7 +661,7 @@ def main():
         p = int(pairs.item()) if torch.is_tensor(pairs) else int(pairs)
         c = classes.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, gather_bytes=0.0, exec_flops=0.0))
         ex = 0.0 if name.startswith("narrow") else 2.0 * 32 * active_slots(gmask, n_out) * cin * ((cout + 31) // 32 * 32)
-        ms = e0.elapsed_time(e1)
+        ms = e0.elapsed_time(e1) if e0 is not None else 0.0      # launches below sp.PROFILER_MIN_ROWS rows carry no events
         launches.append((ms, name, cin, cout, n_out, p, ex))
         c["exec_flops"] += ex
         c["launches"] += 1

@@ -557,14 +557,20 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
     x3 = (INFER_X3 and not bf16 and cin % 32 == 0 and ((cout + 31) // 32 * 32) % 64 == 0 and n_in * cin * 4 < 0xFFFFF000
           and (nbr is None or n_out * K * 4 < 0xFFFFF000))
     prof = PROFILER
-    if prof is None and not bf16 and not x3 and not CONV_T16:
+    timed = prof is not None and n_out >= PROFILER_MIN_ROWS
+    if not timed and not bf16 and not x3 and not CONV_T16:
         # the default inference launch, without the bookkeeping of the other modes (a hundred of these per small frame)
         check(L.pcc_conv_fwd16(x_feats.data_ptr(), n_in, cin, w.data_ptr(), None if wp is None else wp.data_ptr(),
                                None if bias is None else bias.data_ptr(), None if nbr is None else nbr.data_ptr(),
                                None if order is None else order.data_ptr(), None if gmask is None else gmask.data_ptr(), None, K,
                                out.data_ptr(), n_out, cout, act, None if film is None else film.data_ptr(),
                                None if residual is None else residual.data_ptr(), _lib.stream()))
+        if prof is not None:                          # counted (FLOPs, launches), not bracketed by events
+            prof.append((("conv", "", nbr is not None), cin, cout, pairs if pairs is not None else n_out, n_out, None, None, gmask))
         return out
+    log, ev0, ev1 = prof, None, None
+    if not timed:
+        prof = None
     if prof is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
@@ -586,9 +592,10 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
             gmask = g16                              # the profiler's issued-row count follows the tile height
     if prof is not None:
         ev1.record()
+    if log is not None:
         # the launch's name is worked out by the reader (profiled_name): string building has no place between two launches
-        prof.append((("conv", "[bf16]" if bf16 else "[x3]" if x3 else "", nbr is not None), cin, cout,
-                     pairs if pairs is not None else n_out, n_out, ev0, ev1, gmask))
+        log.append((("conv", "[bf16]" if bf16 else "[x3]" if x3 else "", nbr is not None), cin, cout,
+                    pairs if pairs is not None else n_out, n_out, ev0, ev1, gmask))
     return out
 
 
@@ -753,6 +760,9 @@ GATE_LOG = None
 # (kernel class, cin, cout, pairs (device scalar or int), n_out, start event, end event).  The
 # events are recorded on the stream the kernel is launched on (torch's current stream).
 PROFILER = None
+# Launches of fewer output rows are logged without their two events (4.6 us of host time each — more than such a launch takes
+# on the device, in the stretches of a frame where the host is what the GPU waits for); bench.py --breakdown sets it to 0.
+PROFILER_MIN_ROWS = 65536
 
 
 CONV_BM32_MAX = int(os.environ.get("PCC_CONV_BM32_MAX", "3000"))      # mirrors csrc/conv.hip's tile switch (launch names only)
