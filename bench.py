@@ -350,14 +350,16 @@ def main():
     # building the model — and takes 80-135 ms in this process; the per-launch records below (events, tuples) age into the old
     # generation and provoke exactly one during the timed steps (always the 9th of 20: 173-237 ms instead of 99; a plain
     # compress / decompress loop without the records ran 24 frames without one).  Everything alive now is moved out of the
-    # collector's reach (gc.freeze(): what a long-running coder process should do after loading its model — README); a full
-    # collection then walks what the steps created, a millisecond or two.  The collector itself STAYS ON: the coordinate maps
-    # of a frame reference each other, only the collector frees them, and they hold device memory — with it off every step
-    # went to hipMalloc for new blocks (83 calls in 20 steps against 8).  PCC_BENCH_GC_OFF=1 switches it off all the same (A/B).
+    # collector's reach (gc.freeze(): what a long-running coder process should do after loading its model — README), and
+    # automatic collection is off for the K timed steps, as timeit does (a collection of what the steps and this script's log
+    # create still cost 10-20 ms when one fell into a step).  Nothing leaks meanwhile: a frame's coordinate maps no longer
+    # reference each other in cycles (sparse._same_map), so their device memory goes back to the allocator by reference count —
+    # `device_allocs_during_timed_steps` is 4 with the collector on or off (83 against 8 while the cycles existed).
+    # PCC_BENCH_GC_OFF=0 leaves the collector on (A/B).
     import gc
     gc.collect()
     gc.freeze()
-    if os.environ.get("PCC_BENCH_GC_OFF", "0") == "1":
+    if os.environ.get("PCC_BENCH_GC_OFF", "1") == "1":
         gc.disable()
     allocs_before = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     if dist is not None:
@@ -816,8 +818,9 @@ def main():
         "t_dec_ms": t_dec / args.steps * 1e3,
         "step_ms": step_ms,
         "device_allocs_during_timed_steps": device_allocs_timed,     # hipMalloc calls of the caching allocator inside the timed region
-        "gc": "objects alive after warm-up frozen (gc.freeze()), collector on: a full collection otherwise walks ~215 k interpreter "
-              "objects (80-135 ms) and the per-launch records of this script provoke one per 20 steps",
+        "gc": "objects alive after warm-up frozen (gc.freeze()), automatic collection off during the timed steps: a full collection "
+              "otherwise walks ~215 k interpreter objects (80-135 ms) and the per-launch records of this script provoke one per 20 "
+              "steps; no device memory depends on the collector (device_allocs_during_timed_steps)",
         "bpp": bpp,
         "conv_gflop_per_step": sum(c["flops"] for c in classes.values()) / args.steps / 1e9,
         "roofline": roofline,

@@ -11,6 +11,7 @@ Everything numeric runs in the HIP library; torch provides device memory, stream
 parameter containers only.
 """
 import math
+import weakref
 
 import os
 
@@ -133,6 +134,17 @@ class PairCount:
         return float(self.item())
 
 
+def _same_map(kept, out_map, self_map):
+    """is a cached kernel map the one for `out_map`?  Entries are keyed by id(out_map) and remember the map itself — weakly:
+    a strong reference makes a cycle wherever an output map is an ancestor of the input map (h_s back onto y's coordinates:
+    y.map -> "down" -> ... -> z.map -> this entry -> y.map), and a frame's maps, with the device memory of their tables and
+    kernel maps, then wait for the cyclic collector instead of going back to the allocator when the frame is done.  A dead
+    reference is a miss, so an id reused by a new map can never hit an old entry."""
+    if kept is None:
+        return out_map is self_map
+    return kept() is out_map
+
+
 class CoordMap:
     """A coordinate set of one tensor stride with its hashed-voxel table and cached kernel maps.
 
@@ -215,7 +227,7 @@ class CoordMap:
         """(nbr int32 [N_out, K], row_mask int32 [N_out], PairCount) for input=self, output=out_map."""
         key = ("kmap", id(out_map), ksize, transposed)
         hit = self._cache.get(key)
-        if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
+        if hit is not None and _same_map(hit[0], out_map, self):
             return hit[1:]
         keys, vals, cap = self.table()
         K = ksize ** 3
@@ -226,9 +238,8 @@ class CoordMap:
         check(_lib.lib().pcc_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step,
                                         -1 if transposed else 1, ptr(nbr), ptr(row_mask), None, _lib.stream()))
         pairs = PairCount(row_mask)
-        # keep out_map alive so its id() stays unique -- except for self (that would be a reference
-        # cycle holding gigabytes of device memory until the cyclic GC runs)
-        self._cache[key] = (None if out_map is self else out_map, nbr, row_mask, pairs)
+        # the entry remembers out_map weakly (_same_map): id() alone could be reused, a strong reference makes cycles
+        self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr, row_mask, pairs)
         return nbr, row_mask, pairs
 
     def ordered_kernel_map(self, out_map, ksize, transposed=False):
@@ -238,7 +249,7 @@ class CoordMap:
         that 32-row MFMA tiles skip the offsets none of their rows has."""
         key = ("okmap", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)
         hit = self._cache.get(key)
-        if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
+        if hit is not None and _same_map(hit[0], out_map, self):
             return hit[1:]
         if (0 < out_map.n <= _small_map_max() and ksize in (2, 3) and ORDER_BLOCK_LOG2 < 0 and not _ORDER_KEY_OVERRIDE
                 and ("kmap", id(out_map), ksize, transposed) not in self._cache):
@@ -256,7 +267,7 @@ class CoordMap:
         check(L.pcc_order_rows_by_mask16(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
                                          ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch), nbytes,
                                          _lib.stream()))
-        self._cache[key] = (None if out_map is self else out_map, nbr_sorted, order, gmask, pairs)
+        self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr_sorted, order, gmask, pairs)
         self._cache[("gmask16",) + key[1:]] = gmask16
         return nbr_sorted, order, gmask, pairs
 
@@ -278,7 +289,7 @@ class CoordMap:
                                      ptr(nbr), ptr(row_mask), ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch),
                                      nbytes, _lib.stream()))
         pairs = PairCount(row_mask)
-        keep = None if out_map is self else out_map
+        keep = None if out_map is self else weakref.ref(out_map)
         self._cache[("kmap", id(out_map), ksize, transposed)] = (keep, nbr, row_mask, pairs)
         self._cache[key] = (keep, nbr_sorted, order, gmask, pairs)
         self._cache[("gmask16",) + key[1:]] = gmask16
@@ -295,7 +306,7 @@ class CoordMap:
         convolutions run on: rows stay in the map's own order, every MFMA tile holds 32 list entries."""
         key = ("cmap", id(out_map), ksize, transposed)
         hit = self._cache.get(key)
-        if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is self)):
+        if hit is not None and _same_map(hit[0], out_map, self):
             return hit[1:]
         nbr, _, pairs = self.kernel_map(out_map, ksize, transposed)
         L = _lib.lib()
@@ -306,7 +317,7 @@ class CoordMap:
         ent_row4 = torch.empty((groups, K, 2, 32), dtype=torch.int32, device=dev)
         cnt = torch.empty((groups, 32), dtype=torch.int16, device=dev)
         check(L.pcc_compact_map(ptr(nbr), n_out, K, ptr(ent_in), ptr(ent_row4), ptr(cnt), _lib.stream()))
-        self._cache[key] = (None if out_map is self else out_map, ent_in, ent_row4, cnt, pairs)
+        self._cache[key] = (None if out_map is self else weakref.ref(out_map), ent_in, ent_row4, cnt, pairs)
         return ent_in, ent_row4, cnt, pairs
 
     def mfma_kernel_map(self, out_map, ksize, transposed=False):
