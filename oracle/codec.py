@@ -73,7 +73,8 @@ def up_block_predict(p, x, k, dense=True, condition_ablation=None):
         x = conv_2(x)
     h = p.sub("occ_predict").conv(x, "0")
     h = on.relu(h)
-    pred = p.sub("occ_predict").conv(h, "2")
+    # only channel 0 is ever read (blocks.py:142); in "kernel" order it is evaluated the way the product evaluates it: alone
+    pred = p.sub("occ_predict").conv(h, "2", out_channels=1 if on.ORDER == "kernel" else None)
     mask = topk_mask(pred, k)
     up_coords = pred.C[mask]
     x = prune_by_coords(x, up_coords)

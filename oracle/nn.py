@@ -6,6 +6,14 @@ tensor ``[K, C_in, C_out]`` (``[C_in, C_out]`` for kernel_size 1) and bias
 ``[1, C_out]``, accumulated per kernel offset in fixed order k = 0..K-1
 (gather -> sgemm -> index_add_).
 
+Two summation orders (``set_order``):
+  * ``"blas"`` (default): the above — an independent statement of the operator, whose fp32 sums differ from the
+    product's in the last bits (MKL's blocking against the MFMA chain); comparisons against it carry tolerances.
+  * ``"kernel"``: every output element is ONE fused multiply-add chain in the order the product's kernels document
+    (oracle/chain.c), including which layer shapes the product evaluates as a thin kernel, an MFMA tile or a narrow head
+    (scores per input row, then a plain sum over the offsets).  Against this mode latents, streams and decoded voxel
+    sets are compared for EQUALITY (tests/test_exact_parity.py).
+
 Test infrastructure only — see oracle/__init__.py.
 """
 from dataclasses import dataclass, field
@@ -44,11 +52,44 @@ class SparseTensor:
         return SparseTensor(self.C[order], self.F[torch.from_numpy(order)], self.stride)
 
 
+ORDER = "blas"
+NARROW_HEAD_MAX_COUT = 4          # the product's rule (pcc_amd/sparse.py: conv_forward): cout <= 4 on inputs of a multiple of 32 channels
+
+
+def set_order(order):
+    """"blas" or "kernel" (module docstring); returns the previous order"""
+    global ORDER
+    assert order in ("blas", "kernel"), order
+    was, ORDER = ORDER, order
+    return was
+
+
+def _apply_conv_kernel_order(F_in, W, bias, nbr, n_out):
+    """The product's summation order, layer shape by layer shape (csrc/conv.hip; dispatch in pcc_amd/sparse.py:conv_forward):
+    cin % 32 != 0 -> thin kernel, channels ascending; cin % 32 == 0 -> MFMA visit order; kernel_size > 1 with cout <= 4 on
+    such inputs -> narrow head: scores[i, k, c] = in[i] . W[k][:, c] (an MFMA chain per input row), out = sum_k scores."""
+    from . import chain
+    K, cin, cout = W.shape
+    F_np, W_np = F_in.detach().numpy(), W.detach().numpy()
+    if nbr is not None and K > 1 and cin % 32 == 0 and cout <= NARROW_HEAD_MAX_COUT:
+        w_r = np.ascontiguousarray(np.transpose(W_np, (1, 0, 2)).reshape(1, cin, K * cout))
+        scores = chain.conv_chain(F_np, w_r, None, F_np.shape[0], True)
+        out = chain.gather_sum(scores, nbr, cout)
+    else:
+        out = chain.conv_chain(F_np, W_np, nbr, n_out, cin % 32 == 0)
+    out = torch.from_numpy(out)
+    if bias is not None:
+        out = out + bias.reshape(1, -1)          # the epilogue adds the bias to the finished accumulator (csrc/conv.hip:861)
+    return out
+
+
 def _apply_conv(F_in, W, bias, nbr, n_out):
     K = nbr.shape[1]
     if W.dim() == 2:
         W = W[None]
     assert W.shape[0] == K, (W.shape, K)
+    if ORDER == "kernel":
+        return _apply_conv_kernel_order(F_in, W, bias, nbr, n_out)
     out = torch.zeros((n_out, W.shape[2]), dtype=torch.float32)
     for k in range(K):
         col = nbr[:, k]
@@ -67,6 +108,10 @@ def conv(x, W, bias=None, ksize=3, stride=1):
     if ksize == 1:
         assert stride == 1
         Wk = W if W.dim() == 2 else W[0]
+        if ORDER == "kernel":
+            y = SparseTensor(x.C, _apply_conv_kernel_order(x.F, Wk[None], bias, None, x.C.shape[0]), x.stride)
+            y._cache = x._cache
+            return y
         out = x.F @ Wk
         if bias is not None:
             out = out + bias.reshape(1, -1)
@@ -168,9 +213,16 @@ class Params:
         v = self.sd.get(self.prefix + name, default)
         return None if v is None else torch.as_tensor(v, dtype=torch.float32)
 
-    def conv(self, x, name, ksize=3, stride=1):
+    def conv(self, x, name, ksize=3, stride=1, out_channels=None):
+        """``out_channels``: evaluate only the first columns of the kernel (where the reference reads only channel 0,
+        blocks.py:142).  A column's value does not depend on the others in "blas" order up to BLAS blocking; in "kernel"
+        order the narrower layer is the shape the product evaluates (a narrow head), so the slice is part of the order."""
         p = self.sub(name)
-        y = conv(x, p.get("kernel"), p.get("bias"), ksize, stride)
+        W, b = p.get("kernel"), p.get("bias")
+        if out_channels is not None:
+            W = W[..., :out_channels].contiguous()
+            b = None if b is None else b.reshape(-1)[:out_channels].contiguous()
+        y = conv(x, W, b, ksize, stride)
         y.tag = self.prefix + name            # the layer's state_dict name: keys FORCED_GATES
         return y
 

@@ -102,8 +102,53 @@ def entropy_kats():
     }
 
 
+KERNEL_ORDER_FRAMES = {           # name -> (shell, (q_g, q_a)); the shells of tests/test_hip_codec.py and tests/test_exact_parity.py
+    "config1_32": (dict(grid=32, radius=15.0, half_width=0.875), (0.5, 0.5)),
+    "shell_64_q01_02": (dict(grid=64, radius=27.0, half_width=0.6), (0.1, 0.2)),
+    "shell_96": (dict(grid=96, radius=40.0, half_width=0.5), (0.5, 0.5)),
+}
+
+
+def recon_sha(rec):
+    """sha256 of the decoded cloud in canonical (x, y, z) order: int32 coordinates, then the colours as 8-bit integers"""
+    order = np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))
+    geo = np.ascontiguousarray(rec[order, :3].astype(np.int32)).tobytes()
+    col = np.ascontiguousarray(np.rint(rec[order, 3:6] * 255.0).astype(np.uint8)).tobytes()
+    return sha(geo), sha(col)
+
+
+def kernel_order_frames():
+    """The oracle in "kernel" summation order (oracle/chain.c: one fused multiply-add chain per output element, no BLAS):
+    its bytes do not depend on the host's BLAS, thread count or vector width, and the product must reproduce them EXACTLY —
+    streams, latent coordinates, decoded geometry and 8-bit colours (tests/test_golden.py on the CPU for the oracle,
+    tests/test_exact_parity.py on the GPU for the HIP path)."""
+    from oracle import nn as on
+    syn = pcc_amd.synthetic
+    model = syn.make_model(seed=0, device="cpu")
+    codec = Codec(model.state_dict())
+    codec.update()
+    out = {}
+    was = on.set_order("kernel")
+    try:
+        for name, (shell, (qg, qa)) in KERNEL_ORDER_FRAMES.items():
+            pts = syn.sphere_shell(**shell)
+            qc, qf = syn.uniform_qmap(pts[:, :3], qg, qa)
+            strings, shape, k, coords = codec.compress(pts, qc, qf)
+            rec = codec.decompress(coords, strings, shape, k)
+            geo, col = recon_sha(rec)
+            out[name] = {"shell": shell, "q": [qg, qa], "n_points": int(pts.shape[0]), "k": k, "shape": shape,
+                         "len_y": len(strings[0][0]), "len_z": len(strings[1][0]),
+                         "sha256_y": sha(strings[0][0]), "sha256_z": sha(strings[1][0]),
+                         "latent_coords_sha256": sha(np.ascontiguousarray(coords[oc.sort_order(coords)]).tobytes()),
+                         "recon_geometry_sha256": geo, "recon_colour_sha256": col}
+    finally:
+        on.set_order(was)
+    return out
+
+
 if __name__ == "__main__":
-    fixtures = {"config1_oracle": config1(), "integer_kats": integer_kats(), "entropy_kats": entropy_kats()}
+    fixtures = {"config1_oracle": config1(), "integer_kats": integer_kats(), "entropy_kats": entropy_kats(),
+                "kernel_order_frames": kernel_order_frames()}
     for name, obj in fixtures.items():
         with open(os.path.join(HERE, name + ".json"), "w") as f:
             json.dump(obj, f, indent=1, sort_keys=True)

@@ -1,0 +1,157 @@
+"""GPU: the HIP codec against the oracle in "kernel" summation order — EQUALITY, not tolerances.
+
+Every other HIP-vs-oracle comparison (tests/_parity.py) carries a tolerance, because the default oracle sums its
+convolutions in BLAS order and fp32 addition is not associative: the ~1e-7 relative differences are then "explained by
+summation order", which is an explanation and not a check.  Here the oracle states each output element as ONE fused
+multiply-add chain in the order the kernels document for themselves (oracle/chain.c, oracle/nn.py "kernel"), the rest of
+the codec being single correctly-rounded operations on both sides (quantisers, table look-ups, FiLM, activations, top-k,
+colour rounding; reference: model/entropy_models.py:341-414, model/blocks.py:130-150).  Then nothing is left to explain:
+
+  * the y and z streams are byte-equal (and equal to the committed sha256 of tests/golden/kernel_order_frames.json);
+  * k, shape and the latent coordinates are equal;
+  * the decoded latents y_hat and the decoded q-map Q_hat are equal value for value;
+  * the decoded voxel sets are identical (0 flips) and so is every 8-bit colour.
+
+A failure here is a finding about a kernel's accumulation order (or about a non-deterministic operation), not noise.
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import nn as on
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def model(pcc):
+    m = pcc.synthetic.make_model(0, DEV)
+    m.update()
+    return m
+
+
+@pytest.fixture()
+def kernel_order():
+    was = on.set_order("kernel")
+    yield
+    on.set_order(was)
+
+
+def canonical(rec):
+    """decoded cloud in (x, y, z) order as (int32 coordinates, uint8 colours)"""
+    order = np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))
+    return rec[order, :3].astype(np.int32), np.rint(rec[order, 3:6] * 255.0).astype(np.uint8)
+
+
+def exact_compare(pcc, model, oracle_codec, pts, qc, qf, tag):
+    """-> dict of what was measured; asserts the equalities of the module docstring"""
+    x = torch.from_numpy(pts).to(DEV)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    strings, shape, k, coords = model.compress(x, Q)
+    t0 = time.time()
+    o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
+    t_enc = time.time() - t0
+    assert shape == o_shape and k == o_k, tag
+    got_c = coords.cpu().numpy()
+    assert np.array_equal(got_c[oc.sort_order(got_c)], o_coords[oc.sort_order(o_coords)]), (tag, "latent coordinates")
+    # the encoder's latents, before any coding: g_a + h_a on both sides (the oracle keeps its own in .last)
+    n_y = strings[0][0] != o_strings[0][0]
+    n_z = strings[1][0] != o_strings[1][0]
+    # decode each side's own stream
+    c8 = pcc.CoordMap(coords.to(torch.int32).contiguous(), 8, nbatch=len(k[0]))
+    with torch.no_grad():
+        y_hat, Q_hat = model.entropy_model.decompress([c8, c8.down().down()], strings, shape)
+    rec = model.reconstruct(y_hat, Q_hat, k).cpu().numpy()
+    t0 = time.time()
+    o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+    t_dec = time.time() - t0
+    o_y, o_Q = oracle_codec.last_dec["y_hat"], oracle_codec.last_dec["Q_hat"]
+    assert np.array_equal(y_hat.C.cpu().numpy(), o_y.C), (tag, "y_hat rows")            # both in canonical (bitstream) order
+    dy = int((y_hat.F.cpu() != o_y.F).sum())
+    # Q_hat: row orders may differ (generated coordinates): align through the coordinates
+    qh_c, qh_f = Q_hat.C.cpu().numpy(), Q_hat.F.cpu().numpy()
+    og, orf = oc.sort_order(qh_c), oc.sort_order(o_Q.C)
+    assert np.array_equal(qh_c[og], o_Q.C[orf]), (tag, "Q_hat support")
+    dq = int((qh_f[og] != o_Q.F.numpy()[orf]).sum())
+    geo, col = canonical(rec)
+    o_geo, o_col = canonical(o_rec)
+    flips = len(set(map(tuple, geo.tolist())) ^ set(map(tuple, o_geo.tolist())))
+    dcol = int((col != o_col).sum()) if flips == 0 else -1
+    r = dict(tag=str(tag), n=int(pts.shape[0]), y_stream_equal=not n_y, z_stream_equal=not n_z, y_hat_differing=dy, q_hat_differing=dq,
+             voxel_flips=flips, colours_differing=dcol, oracle_enc_s=round(t_enc, 2), oracle_dec_s=round(t_dec, 2),
+             sha256_y=sha(strings[0][0]), sha256_z=sha(strings[1][0]), strings=strings, coords=got_c, rec=rec)
+    print({k_: v for k_, v in r.items() if k_ not in ("strings", "coords", "rec")})
+    assert not n_z, (tag, "z stream differs: h_a / g_a are not the documented chains")
+    assert not n_y, (tag, "y stream differs", dy)
+    assert dy == 0 and dq == 0, (tag, "decoded latents differ", dy, dq)
+    assert flips == 0, (tag, "decoded voxel sets differ", flips)
+    assert dcol == 0, (tag, "decoded colours differ", dcol)
+    return r
+
+
+@pytest.mark.parametrize("name", ["config1_32", "shell_64_q01_02", "shell_96"])
+def test_streams_and_reconstruction_equal_the_kernel_order_oracle_and_its_golden_hashes(pcc, model, oracle_codec, kernel_order, name):
+    from make_golden import KERNEL_ORDER_FRAMES, recon_sha
+    with open(os.path.join(GOLD, "kernel_order_frames.json")) as f:
+        want = json.load(f)[name]
+    shell, (qg, qa) = KERNEL_ORDER_FRAMES[name]
+    pts = pcc.synthetic.sphere_shell(**shell)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], qg, qa)
+    r = exact_compare(pcc, model, oracle_codec, pts, qc, qf, name)
+    # and against the committed bytes (made on the build container's CPU by tests/golden/make_golden.py)
+    assert (r["sha256_y"], r["sha256_z"]) == (want["sha256_y"], want["sha256_z"]), name
+    assert sha(np.ascontiguousarray(r["coords"][oc.sort_order(r["coords"])]).tobytes()) == want["latent_coords_sha256"], name
+    assert recon_sha(r["rec"]) == (want["recon_geometry_sha256"], want["recon_colour_sha256"]), name
+
+
+def test_256_cube_frame_equals_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order):
+    """125,672 points: the mid-size launches (32-row tiles, 64 x 64 tiles) and the large-launch kernels in one frame"""
+    pts = pcc.synthetic.sphere_shell(grid=256, radius=100.0, half_width=0.5)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    exact_compare(pcc, model, oracle_codec, pts, qc, qf, "256^3")
+
+
+@pytest.mark.parametrize("q", [(0.05, 0.1), (1.0, 1.0)])
+def test_other_operating_points_equal_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order, q):
+    """the q-map moves every FiLM scale and the latents' scales: the two ends of the grid of plot.py:31-32"""
+    pts = pcc.synthetic.sphere_shell(grid=64, radius=27.0, half_width=0.6)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], *q)
+    exact_compare(pcc, model, oracle_codec, pts, qc, qf, ("64^3", q))
+
+
+def test_irregular_geometry_equals_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order):
+    """scattered voxels + a filled block + a plane + per-point random q-map: sparse masks, ragged tiles, dense neighbourhoods"""
+    rng = np.random.default_rng(11)
+    parts = [rng.integers(0, 96, (4000, 3)),
+             np.stack(np.meshgrid(np.arange(20, 36), np.arange(20, 36), np.arange(20, 36), indexing="ij"), -1).reshape(-1, 3),
+             np.stack(np.meshgrid(np.arange(0, 96), np.arange(0, 96), np.array([64]), indexing="ij"), -1).reshape(-1, 3)]
+    xyz = np.unique(np.concatenate(parts), axis=0).astype(np.float32)
+    rgb = (rng.integers(0, 256, (xyz.shape[0], 3)) / 255.0).astype(np.float32)
+    pts = np.concatenate([xyz, rgb], axis=1)
+    qc = np.concatenate([np.zeros((xyz.shape[0], 1), np.float32), xyz], axis=1)
+    qf = rng.random((xyz.shape[0], 2)).astype(np.float32)
+    exact_compare(pcc, model, oracle_codec, pts, qc, qf, "irregular")
+
+
+def test_full_config2_frame_equals_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order):
+    """BASELINE config 2 at its stated size (N = 850,824): 2.46 M + 0.15 M latents, 8.7 TFLOP of chains on the host cores
+    (~30-60 s): the y and z streams byte-equal, every decoded latent, voxel and colour equal"""
+    syn = pcc.synthetic
+    pts = syn.sphere_shell(**syn.CONFIG2)
+    assert pts.shape[0] == 850_824
+    qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    exact_compare(pcc, model, oracle_codec, pts, qc, qf, "config 2, full size")

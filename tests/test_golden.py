@@ -98,3 +98,61 @@ def test_config1_oracle_end_to_end(pcc, seeded_state_dict, oracle_codec):
         assert abs(len(strings[0][0]) - g["len_y"]) <= 0.01 * g["len_y"] + 8
         assert abs(count_bits(strings) / pts.shape[0] - g["bpp"]) <= 5e-3 * g["bpp"]
         assert abs(met["sym_psnr_mse"] - g["d1_psnr"]) < 0.05 and abs(met["sym_y_psnr"] - g["y_psnr"]) < 0.05
+
+
+def test_kernel_order_oracle_reproduces_its_golden_bytes(pcc, oracle_codec):
+    """The oracle in "kernel" summation order (oracle/chain.c) is plain fused multiply-add chains — no BLAS, so its bytes
+    are the same on every host: streams, latent coordinates, decoded geometry and colours must equal the committed hashes
+    exactly.  The GPU twin of this test (tests/test_exact_parity.py) holds the HIP path to the same hashes."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import KERNEL_ORDER_FRAMES, recon_sha
+    from oracle import nn as on
+    g = load("kernel_order_frames")
+    assert set(g) == set(KERNEL_ORDER_FRAMES)
+    syn = pcc.synthetic
+    was = on.set_order("kernel")
+    try:
+        for name, (shell, (qg, qa)) in KERNEL_ORDER_FRAMES.items():
+            want = g[name]
+            pts = syn.sphere_shell(**shell)
+            qc, qf = syn.uniform_qmap(pts[:, :3], qg, qa)
+            strings, shape, k, coords = oracle_codec.compress(pts, qc, qf)
+            assert (pts.shape[0], k, shape) == (want["n_points"], want["k"], want["shape"]), name
+            assert (sha(strings[0][0]), sha(strings[1][0])) == (want["sha256_y"], want["sha256_z"]), name
+            assert sha(np.ascontiguousarray(coords[oc.sort_order(coords)]).tobytes()) == want["latent_coords_sha256"], name
+            rec = oracle_codec.decompress(coords, strings, shape, k)
+            assert recon_sha(rec) == (want["recon_geometry_sha256"], want["recon_colour_sha256"]), name
+    finally:
+        on.set_order(was)
+
+
+def test_chain_convolution_equals_its_scalar_statement():
+    """oracle/chain.c: the vectorised, windowed, threaded chain against the four-line scalar loop it restates, bit for bit,
+    over thin / MFMA-order / narrow shapes, kernel sizes 1, 2, 3, sparse and dense neighbourhoods"""
+    from oracle import chain
+    rng = np.random.default_rng(5)
+    for (n_in, n_out, cin, cout, K, mfma, dens) in [(300, 500, 64, 64, 27, 1, 0.4), (300, 200, 128, 1, 27, 1, 0.8), (3000, 1999, 16, 2, 27, 0, 0.1),
+                                                    (997, 997, 128, 128, 1, 1, 1.0), (500, 1000, 128, 192, 8, 1, 0.12), (40, 40, 2, 128, 27, 0, 0.5),
+                                                    (7, 5, 32, 3, 27, 1, 0.5), (64, 64, 192, 256, 27, 1, 0.05)]:
+        fin = rng.standard_normal((n_in, cin)).astype(np.float32)
+        w = rng.standard_normal((K, cin, cout)).astype(np.float32)
+        nbr = None
+        if K > 1:
+            nbr = rng.integers(0, n_in, (n_out, K))
+            nbr[rng.random((n_out, K)) > dens] = -1
+        else:
+            n_out = n_in
+        a = chain.conv_chain(fin, w, nbr, n_out, mfma)
+        b = chain.conv_chain(fin, w, nbr, n_out, mfma, scalar=True)
+        assert np.array_equal(a, b), (n_in, n_out, cin, cout, K, mfma)
+    # the visit order matters (else the two orders would be one): MFMA order differs from ascending order somewhere
+    fin = rng.standard_normal((50, 64)).astype(np.float32)
+    w = rng.standard_normal((1, 64, 32)).astype(np.float32)
+    assert not np.array_equal(chain.conv_chain(fin, w, None, 50, True), chain.conv_chain(fin, w, None, 50, False))
+    # and a hand-checkable case: one row, one offset, 8 channels of powers of two whose sum depends on the order
+    x = np.array([[2.0 ** 24, 1.0, 1.0, 1.0, -2.0 ** 24, 1.0, 1.0, 1.0]], np.float32)
+    w1 = np.ones((1, 8, 1), np.float32)
+    asc = chain.conv_chain(x, w1, None, 1, False)[0, 0]       # ((2^24 + 1 + 1 + 1) - 2^24) + 1 + 1 + 1: the first three ones are absorbed
+    vis = chain.conv_chain(x, w1, None, 1, True)[0, 0]        # 2^24 - 2^24 first (channels 0, 4), then six ones
+    assert (asc, vis) == (3.0, 6.0), (asc, vis)
