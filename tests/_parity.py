@@ -1,25 +1,37 @@
-"""Shared tolerance rule of the HIP-vs-oracle codec comparisons.
+"""Shared rules of the HIP-vs-oracle codec comparisons.
 
-BASELINE.json asks for D1-PSNR / Y-PSNR within 1e-3 dB.  That is the tolerance whenever both decoders keep the
-same voxels.  The decoder's top-k (blocks.py:130-150) is discontinuous: with seeded random weights the occupancy
-logits are near-ties, and a 1-ulp difference between MFMA and MKL summation order can keep a different voxel.
-Each voxel that differs between the two decoded sets changes at most its own term of the mean squared error, so
-it may add at most ``flip_bound_db`` to the difference — the bound is computed from the oracle's own MSE and is
-zero when the sets agree.
+Two oracles, two kinds of statement (oracle/nn.py):
 
-``compare_codec`` splits a codec comparison into the stages where two fp32 implementations can legitimately part:
-  * the encoder's discrete decisions: a latent whose y - mu sits on a rounding boundary may be coded one step apart,
-    and a scale on a table boundary may pick the neighbouring CDF (same symbol, different bytes) — streams need not be
-    byte-equal and cannot always be cross-decoded, like the reference's own CPU and GPU builds; counted and bounded;
-  * the decoder on IDENTICAL latents (the oracle's decoded y_hat and Q_hat through the HIP synthesis): here only
-    top-k near-ties remain, and the 1e-3 dB bound applies in full;
-  * end to end on each side's own stream: the 1e-3 dB bound when no latent was rounded differently, otherwise a
-    stated allowance per differently-rounded latent (a different, equally valid encoding of the same frame).
+* **"kernel" order — equality.**  The oracle sums every convolution as the one fused multiply-add chain the kernels
+  document (oracle/chain.c).  Against it the HIP codec must produce the SAME BYTES: y and z streams, latent coordinates,
+  k, decoded voxels and 8-bit colours (``assert_exact``).  Every ``compare_codec`` call checks this unless told not to.
+
+* **"blas" order — the contract's tolerances.**  The independent restatement (gather -> sgemm -> index_add_, MKL's
+  summation order).  BASELINE.json asks for bpp and D1 / Y-PSNR within 1e-3 (dB) on identical inputs.  On the BASELINE
+  configurations (``strict=True``: configs 1, 2, 3) that bound is asserted DIRECTLY on the end-to-end result — no
+  allowance per differing voxel or per differently-rounded latent.  What the two fp32 implementations legitimately
+  decide differently (a latent whose y - mu sits on .5 within their ~1e-7 difference, a scale on a table boundary, a
+  top-k near-tie) is COUNTED — ``n_sym`` latents a whole step apart, ``flips_same`` voxels with the decoder fed identical
+  latents, ``flips`` voxels end to end — recorded per case in gpurun_out/parity_counts.json and held against the
+  committed tests/golden/parity_counts.json: a count may not exceed twice its committed value (+ 2).
+  The older allowances (a dB bound per differing voxel / per differently-rounded latent) remain only for the adversarial
+  clouds and model variants (``strict=False``: tests/test_random_clouds.py, test_config_variants.py), where seeded random
+  weights amplify one flipped latent of a 1,500-point cloud into more than 1e-3 dB.
 """
+import json
+import os
+
 import numpy as np
 
 D1_WORST_SQ = 64.0      # geometry term = mean over axes of squared offsets: an 8-voxel miss on every axis
 Y_WORST_SQ = 1.0        # luma in [0, 1]
+CONTRACT_DB = 1e-3      # BASELINE.json: D1-PSNR / Y-PSNR within 1e-3 dB
+CONTRACT_BPP = 1e-3     # BASELINE.json: bpp within 1e-3
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+COUNTS_GOLDEN = os.path.join(_HERE, "golden", "parity_counts.json")
+COUNTS_OUT = os.path.join(os.path.dirname(_HERE), "gpurun_out", "parity_counts.json")
+_counts_seen = {}
 
 
 def flip_bound_db(n_flips, n_points, mse, worst_sq):
@@ -34,23 +46,89 @@ def voxel_flips(rec, o_rec):
 
 
 def assert_psnr_parity(m, om, flips, n_points, tag=None):
-    """m / om: pc_metrics of the HIP and the oracle reconstruction against the same source"""
+    """non-strict rule — m / om: pc_metrics of the HIP and the oracle reconstruction against the same source"""
     for key, mse_key, worst in (("sym_psnr_mse", "mse", D1_WORST_SQ), ("sym_y_psnr", "y_mse", Y_WORST_SQ)):
         if not (np.isfinite(m[key]) or np.isfinite(om[key])):
             continue                                         # both lossless
-        tol = 1e-3 + flip_bound_db(flips, n_points, min(om["AB_" + mse_key], om["BA_" + mse_key]), worst)
+        tol = CONTRACT_DB + flip_bound_db(flips, n_points, min(om["AB_" + mse_key], om["BA_" + mse_key]), worst)
         assert abs(m[key] - om[key]) <= tol, (tag, key, m[key], om[key], flips, tol)
 
 
-SYMBOL_FLIP_DB = 0.05       # end-to-end allowance per differently-rounded latent (seeded random weights amplify one step
+def assert_contract(bpp, o_bpp, m, om, tag=None):
+    """strict rule: BASELINE's bounds, directly"""
+    assert abs(bpp - o_bpp) <= CONTRACT_BPP, (tag, "bpp", bpp, o_bpp)
+    for key in ("sym_psnr_mse", "sym_y_psnr"):
+        if np.isfinite(m[key]) or np.isfinite(om[key]):
+            assert abs(m[key] - om[key]) <= CONTRACT_DB, (tag, key, m[key], om[key])
+
+
+SYMBOL_FLIP_DB = 0.05       # non-strict end-to-end allowance per differently-rounded latent (seeded random weights amplify one step
                             # of one latent into ~0.01 dB on a 17 k-point frame; measured, tools/parity_diag.py)
 
 
-def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0"):
-    """HIP codec vs CPU oracle on one frame, stage by stage (module docstring).  Returns a dict of what was measured."""
+def record_counts(tag, counts):
+    """store the discrete-decision counts of one case and hold them against the committed values (module docstring)"""
+    key = tag if isinstance(tag, str) else json.dumps(tag, default=str)
+    _counts_seen[key] = counts
+    try:
+        os.makedirs(os.path.dirname(COUNTS_OUT), exist_ok=True)
+        with open(COUNTS_OUT, "w") as f:
+            json.dump(_counts_seen, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    committed = {}
+    if os.path.exists(COUNTS_GOLDEN):
+        with open(COUNTS_GOLDEN) as f:
+            committed = json.load(f)
+    want = committed.get(key)
+    if want is None:
+        return                                    # a new case: its first run defines the committed value
+    for name, value in counts.items():
+        if name in want and isinstance(value, int):
+            assert value <= 2 * int(want[name]) + 2, (key, name, value, "committed", want[name])
+
+
+def canonical(rec):
+    """decoded cloud in (x, y, z) order as (int32 coordinates, uint8 colours)"""
+    order = np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))
+    return rec[order, :3].astype(np.int32), np.rint(rec[order, 3:6] * 255.0).astype(np.uint8)
+
+
+def assert_exact(oracle_codec, pts, qc, qf, strings, shape, k, coords, rec, tag=None, batch=None, rec_item=None):
+    """the HIP result against the oracle in "kernel" summation order: the same bytes (module docstring)"""
+    from oracle import coords as oc
+    from oracle import nn as on
+    was = on.set_order("kernel")
+    try:
+        o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf, batch=batch)
+        assert shape == o_shape and k == o_k, (tag, "kernel order: shape / k")
+        got_c = np.asarray(coords)
+        assert np.array_equal(got_c[oc.sort_order(got_c)], o_coords[oc.sort_order(o_coords)]), (tag, "kernel order: latent coordinates")
+        assert strings[1][0] == o_strings[1][0], (tag, "kernel order: z stream differs")
+        assert strings[0][0] == o_strings[0][0], (tag, "kernel order: y stream differs")
+        o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+        if rec_item is not None:                                   # batch items may overlap in (x, y, z): compare per item
+            o_item = oracle_codec.last_batch
+            for i in np.unique(o_item):
+                geo, col = canonical(rec[rec_item == i])
+                o_geo, o_col = canonical(o_rec[o_item == i])
+                assert np.array_equal(geo, o_geo) and np.array_equal(col, o_col), (tag, "kernel order: item", int(i))
+            return
+        geo, col = canonical(rec)
+        o_geo, o_col = canonical(o_rec)
+        assert np.array_equal(geo, o_geo), (tag, "kernel order: decoded voxel sets differ", voxel_flips(rec, o_rec))
+        assert np.array_equal(col, o_col), (tag, "kernel order: decoded colours differ", int((col != o_col).sum()))
+    finally:
+        on.set_order(was)
+
+
+def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0", strict=False, exact=True):
+    """HIP codec vs CPU oracle on one frame (module docstring).  Returns a dict of what was measured."""
     import torch
+    from oracle import nn as on
     from oracle.codec import count_bits
     from oracle.metrics import pc_metrics
+    assert on.ORDER == "blas", "compare_codec's tolerances belong to the BLAS-order oracle"
     N = pts.shape[0]
     x = torch.from_numpy(pts).to(dev)
     Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(dev), features=torch.from_numpy(qf).to(dev), device=dev)
@@ -61,7 +139,8 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0")
     got_c = coords.cpu().numpy()
     assert got_c.shape == o_coords.shape and set(map(tuple, got_c.tolist())) == set(map(tuple, o_coords.tolist())), tag
     bpp, o_bpp = count_bits(strings) / N, count_bits(o_strings) / N
-    assert abs(bpp - o_bpp) <= 2e-3 * o_bpp + 1e-3, (tag, bpp, o_bpp)
+    if not strict:
+        assert abs(bpp - o_bpp) <= 2e-3 * o_bpp + 1e-3, (tag, bpp, o_bpp)
     # each side decodes its own stream
     c8 = pcc.CoordMap(coords.to(torch.int32).contiguous(), 8, nbatch=1)
     with torch.no_grad():
@@ -70,12 +149,11 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0")
     o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
     o_y, o_Q = oracle_codec.last_dec["y_hat"], oracle_codec.last_dec["Q_hat"]
     assert rec.shape == o_rec.shape == (N, 6), tag
-    # stage 1, the encoders' discrete decisions: decoded latents equal except for whole quantisation steps
+    # stage 1, the encoders' discrete decisions: decoded latents equal except for whole quantisation steps (counted)
     assert np.array_equal(y_hat.C.cpu().numpy(), o_y.C), tag                   # both in canonical (bitstream) order
     d = (y_hat.F.cpu() - o_y.F).abs()
     stepped = d > 0.5
     n_sym = int(stepped.sum())
-    assert n_sym <= max(2, int(2e-5 * d.numel())), (tag, "latents rounded differently", n_sym)
     assert bool(((d[stepped] - torch.round(d[stepped])).abs() < 1e-3).all()), tag          # whole steps
     assert float(d[~stepped].max()) <= 1e-4 * max(1.0, float(o_y.F.abs().max())), (tag, float(d[~stepped].max()))   # the means agree
     if strings[1] != o_strings[1]:
@@ -85,19 +163,30 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0")
     Qo = pcc.SparseTensor(o_Q.F.to(dev).contiguous(), coordinate_map=pcc.CoordMap(torch.from_numpy(np.ascontiguousarray(o_Q.C, dtype=np.int32)).to(dev), 8, nbatch=1))
     rec_same = model.reconstruct(yo, Qo, k).cpu().numpy()
     flips_same = voxel_flips(rec_same, o_rec)
-    assert flips_same <= max(4, int(2e-3 * N)), (tag, "decoder on identical latents", flips_same)
     om = pc_metrics(pts, o_rec)
-    assert_psnr_parity(pc_metrics(pts, rec_same), om, flips_same, N, (tag, "decoder on identical latents"))
-    # stage 3, end to end on own streams
+    m_same = pc_metrics(pts, rec_same)
     flips = voxel_flips(rec, o_rec)
     m = pc_metrics(pts, rec)
-    if n_sym == 0:
-        # more near-ties than in stage 2: here the two decoders also start from latents whose means differ in the last bits
-        assert flips <= max(8, int(5e-3 * N)), (tag, flips)
-        assert_psnr_parity(m, om, flips, N, tag)                               # 1e-3 dB (+ the voxel-flip bound above)
+    counts = dict(n=int(N), n_sym=n_sym, flips_same=int(flips_same), flips=int(flips))
+    if strict:
+        # BASELINE's bounds directly: the decoder on identical latents, and end to end on own streams
+        assert_contract(o_bpp, o_bpp, m_same, om, (tag, "decoder on identical latents"))
+        assert_contract(bpp, o_bpp, m, om, tag)
+        record_counts(tag, counts)
     else:
-        for key in ("sym_psnr_mse", "sym_y_psnr"):
-            if np.isfinite(m[key]) or np.isfinite(om[key]):
-                assert abs(m[key] - om[key]) <= 1e-3 + SYMBOL_FLIP_DB * n_sym, (tag, key, m[key], om[key], n_sym)
+        assert n_sym <= max(2, int(2e-5 * d.numel())), (tag, "latents rounded differently", n_sym)
+        assert flips_same <= max(4, int(2e-3 * N)), (tag, "decoder on identical latents", flips_same)
+        assert_psnr_parity(m_same, om, flips_same, N, (tag, "decoder on identical latents"))
+        if n_sym == 0:
+            # more near-ties than in stage 2: here the two decoders also start from latents whose means differ in the last bits
+            assert flips <= max(8, int(5e-3 * N)), (tag, flips)
+            assert_psnr_parity(m, om, flips, N, tag)                           # 1e-3 dB (+ the voxel-flip bound above)
+        else:
+            for key in ("sym_psnr_mse", "sym_y_psnr"):
+                if np.isfinite(m[key]) or np.isfinite(om[key]):
+                    assert abs(m[key] - om[key]) <= CONTRACT_DB + SYMBOL_FLIP_DB * n_sym, (tag, key, m[key], om[key], n_sym)
+    if exact:
+        assert_exact(oracle_codec, pts, qc, qf, strings, shape, k, got_c, rec, tag)
     return dict(bpp=bpp, o_bpp=o_bpp, m=m, om=om, flips=flips, flips_same=flips_same, n_sym=n_sym,
-                streams_equal=(strings == o_strings))
+                streams_equal=(strings == o_strings), d_d1=abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]),
+                d_y=abs(m["sym_y_psnr"] - om["sym_y_psnr"]))

@@ -10,10 +10,9 @@ headline's 0.1, which pins (beta, gamma) to (1, 0) and made the four operating p
 pairs must code at >= 3 distinct rates that rise with q, ordered on the GPU as in the oracle; the default initialisation
 keeps one frame as a regression case.
 
-Tolerances (tests/_parity.py, compare_codec): bpp 2e-3 relative; decoded latents equal except for a bounded count of
-whole-step differences on rounding boundaries; the HIP decoder on the oracle's latents within 1e-3 dB D1 / Y-PSNR
-(BASELINE.json) of the oracle's decoder, with the one-voxel-flip bound where top-k near-ties keep different voxels;
-end to end the same 1e-3 dB unless a latent was rounded differently.
+Bounds (tests/_parity.py, compare_codec strict): BASELINE's, asserted directly on every operating point — |bpp| 1e-3,
+|D1| and |Y| 1e-3 dB end to end and with the HIP decoder on the oracle's latents — plus the kernel-order oracle's bytes
+(equality), with the counts of discrete decisions taken differently recorded against tests/golden/parity_counts.json.
 """
 import numpy as np
 import pytest
@@ -49,7 +48,7 @@ def responsive(pcc):
 
 
 def _compare(pcc, model, oracle_codec, pts, qc, qf, tag):
-    r = compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag, DEV)          # stage-by-stage rule: tests/_parity.py
+    r = compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag, DEV, strict=True)          # BASELINE's bounds, directly: tests/_parity.py
     return r["bpp"], r["o_bpp"], r["m"], r["om"], r["flips"]
 
 

@@ -72,7 +72,7 @@ def test_ragged_batch_of_irregular_items_vs_oracle(pcc, model, oracle_codec):
     size and shape that overlap in (x, y, z): 1,500 scattered voxels, 270 voxels on three lines, ONE voxel, a filled block"""
     from oracle.codec import count_bits
     from oracle.metrics import pc_metrics
-    from _parity import assert_psnr_parity, voxel_flips
+    from _parity import assert_exact, assert_psnr_parity, voxel_flips
     rng = np.random.default_rng(11)
     items = [_cloud("scattered", rng), _cloud("lines", rng), np.array([[50, 50, 50, 0.3, 0.6, 0.9]], np.float32),
              _cloud("filled_block", rng)]
@@ -105,3 +105,5 @@ def test_ragged_batch_of_irregular_items_vs_oracle(pcc, model, oracle_codec):
         if len(p) > 1:
             assert_psnr_parity(pc_metrics(p, a), pc_metrics(p, b), f, len(p), ("item", i))
     assert flips <= max(8, int(5e-3 * N)), flips
+    # and byte for byte against the kernel-order oracle on the same items
+    assert_exact(oracle_codec, pts, qc, qf, strings, shape, k, coords.cpu().numpy(), rec, "ragged batch", batch=item, rec_item=rec_item)

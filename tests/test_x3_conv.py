@@ -122,7 +122,7 @@ def test_codec_in_x3_mode_meets_the_oracle_parity_bounds(pcc, oracle_codec):
             s1, rec = code()
             s2, rec2 = code()
             assert s1 == s2 and torch.equal(rec, rec2)                           # deterministic
-            compare_codec(pcc, model, oracle_codec, pts, qc, qf, ("x3", cfg), DEV)   # the fp32 codec's stage-by-stage bounds
+            compare_codec(pcc, model, oracle_codec, pts, qc, qf, ("x3", cfg), DEV, exact=False)   # the fp32 codec's stage-by-stage bounds
         # encoder-side and decoder-side latents agree bit for bit in this mode too
         coords4 = torch.cat([torch.zeros((N, 1), device=DEV, dtype=torch.int32), x[:, :3].to(torch.int32)], dim=1)
         feats = torch.cat([torch.ones((N, 1), device=DEV), x[:, 3:6]], dim=1)
