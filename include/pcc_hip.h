@@ -123,26 +123,23 @@ int pcc_pair_count(const uint32_t* row_mask, int64_t n_out, int64_t* pair_count,
  * mask alone.  Rows with the same neighbour pattern become adjacent, so a 32-row MFMA tile
  * multiplies (almost) no all-zero neighbour rows.  Results do not depend on the order.
  *   order[p]        = output row executed at position p
- *   nbr_sorted[p,:] = nbr[order[p],:]
  *   group_mask32[g] = OR of row_mask over positions 32g .. 32g+31
- * scratch_bytes from pcc_order_scratch_bytes(n).
- *   pcc_order_rows_by_mask16 additionally writes group_mask16[g] = OR over positions 16g .. 16g+15 (may be NULL): the
- *   masks of the 16-row MFMA tiles of pcc_conv_fwd16. */
-int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
-                             int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
-                             uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes, void* stream);
+ * The neighbour table itself stays in output-row order: the convolution kernels read row order[p] of it.
+ * scratch_bytes from pcc_order_scratch_bytes(n). */
 int64_t pcc_order_scratch_bytes(int64_t n);
 int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int64_t n,
-                           int32_t block_log2, int32_t tensor_stride, const int32_t* nbr, int32_t K,
-                           int32_t* order, int32_t* nbr_sorted, uint32_t* group_mask32,
+                           int32_t block_log2, int32_t tensor_stride, int32_t* order, uint32_t* group_mask32,
                            void* scratch, int64_t scratch_bytes, void* stream);
+/* nbr_sorted[p, :] = nbr[order[p], :] — the permuted copy of a table for the weight-gradient kernels of the training
+ * path, which index their table by execution position (pcc_conv_wgrad*). */
+int pcc_permute_map_rows(const int32_t* nbr, const int32_t* order, int64_t n, int32_t K, int32_t* nbr_sorted, void* stream);
 
-/* pcc_kernel_map + pcc_order_rows_by_mask16 (mask order over the whole map: block_log2 < 0) in ONE launch for maps of at
+/* pcc_kernel_map + pcc_order_rows_by_mask (mask order over the whole map: block_log2 < 0) in ONE launch for maps of at
  * most pcc_small_map_max() output rows (256; 0 when PCC_SMALL_MAP=0): a single 1024-thread workgroup probes, counts, builds
- * the keys, sorts and permutes — three launches otherwise (six and a memset above 16,384 rows), each a few microseconds of work
+ * the keys and sorts — three launches otherwise (six and a memset above 16,384 rows), each a few microseconds of work
  * behind its dispatch; from ~300 rows on the probes are too much work for one CU.
- * Outputs as those two calls write them, bit for bit (nbr [n_out, K], row_mask, order, nbr_sorted, group_mask32,
- * group_mask16); scratch_bytes from pcc_order_scratch_bytes(n_out). */
+ * Outputs as those two calls write them, bit for bit (nbr [n_out, K], row_mask, order, group_mask32);
+ * scratch_bytes from pcc_order_scratch_bytes(n_out). */
 int64_t pcc_small_map_max(void);
 /* One-workgroup forms of the small per-map chains, as a bit mask: 1 = execution order (maps of at most 16,384 rows: counts, keys and
  * sort in one launch), 2 = top-k (one batch item, at most 32,768 rows), 4 = coordinate sets (at most 8,192 candidates).  All on
@@ -151,8 +148,7 @@ int64_t pcc_small_map_max(void);
 int32_t pcc_small_paths(int32_t mask);
 int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals, int64_t in_cap,
                          int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* row_mask, int32_t* order,
-                         int32_t* nbr_sorted, uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes,
-                         void* stream);
+                         uint32_t* group_mask32, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Sparse convolution forward (ME.MinkowskiConvolution / *ConvolutionTranspose forward,
@@ -165,10 +161,10 @@ int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_
  * W is the ME kernel tensor [K, cin, cout] (fp32).  For cin % 32 == 0 the MFMA path is used
  * and needs `w_packed` from pcc_conv_pack_weights; otherwise (cin in {1,2,4,8,16}) the
  * thin path reads `w` directly.  nbr == NULL means kernel_size 1 (identity map, K = 1).
- * MFMA path: if `order` != NULL, `nbr` is the permuted table and `group_mask32` the masks from
- * pcc_order_rows_by_mask, and position p computes output row order[p]; with order == NULL rows
- * run in natural order (group_mask32 may then be NULL = every offset executed).
- * film / residual / fout are always indexed by the output row, never by the position.
+ * MFMA path: if `order` != NULL, position p computes output row order[p] and `group_mask32` holds the
+ * masks from pcc_order_rows_by_mask; with order == NULL rows run in natural order (group_mask32 may
+ * then be NULL = every offset executed).
+ * nbr / film / residual / fout are always indexed by the output row, never by the position.
  * MFMA path (also pcc_conv_fwd_bf16, pcc_conv_wgrad*): the gathered tensors (fin, dy) and
  * w_packed must be 16-byte aligned — rows move by 16-byte LDS-DMA loads; PCC_ERR_ARG otherwise.
  * ------------------------------------------------------------------------------------- */
@@ -180,39 +176,12 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
                  const uint32_t* group_mask32, int32_t K, float* fout, int64_t n_out, int32_t cout,
                  int32_t act, const float* film, const float* residual, void* stream);
 
-/* pcc_conv_fwd with 16-row MFMA tiles (v_mfma_f32_16x16x4_f32) on the MFMA path: a 16-row half of a tile skips the
- * offsets none of its rows has (group_mask16 from pcc_order_rows_by_mask16; NULL = pcc_conv_fwd).  Results are
- * bit-identical to pcc_conv_fwd's — one 16x16x4 MFMA runs the same fp32 chain as two chained 32x32x2
- * (tools/micro/mfma_shapes_bitwise.hip) — at the same MFMA throughput; mask-diverse row sets execute fewer empty tiles. */
-int pcc_conv_fwd16(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
-                   const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, const uint32_t* group_mask16, int32_t K,
-                   float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
-
-/* Small launches of pcc_conv_fwd / pcc_conv_fwd16 (map convolutions, cin % 32 == 0, whose 32 x 32 output tiles number at most
+/* Small launches of pcc_conv_fwd (map convolutions, cin % 32 == 0, whose 32 x 32 output tiles number at most
  * `workgroups`, twice that for outputs narrower than 128 columns) run on conv_small_kernel: one 16 x 16 MFMA block per wave,
  * loader waves running the LDS-DMAs ahead — the time of such a launch is one workgroup's serial MFMA chain, which this makes
  * four times shorter (128 -> 128 on 1,136 rows: 27 us against 66).  Results are bit-identical.  Sets the threshold (default
  * 640, or PCC_CONV_SMALL_MAX; 0 = never) and returns the previous one; a negative argument only reads it. */
 int64_t pcc_conv_small_max(int64_t workgroups);
-
-/* Convolution in the map's own row order with compacted offset lists (csrc/conv_co.hip) — the default of the fp32
- * inference path for kernel maps (cin % 32 == 0, cout % 64 == 0).  pcc_compact_map turns a kernel map nbr [n_out, K] into,
- * per group of PCC_COMPACT_GROUP consecutive output rows and per offset k, the list of the group's rows that have a
- * neighbour at k: ent_in [groups, K, PCC_COMPACT_GROUP] int32 (input row of list entry p, -1 = padding), ent_row4
- * [groups, K, 2, 32] uint32 (byte i of word (sp, r) = group-local output row of entry 32 (sp + 2 i) + r; a padding
- * entry names a row of the group that is not in the list) and cnt [groups, 32] uint16 passed as bytes [groups, 64]
- * (list lengths 0 .. 256); groups = pcc_compact_map_groups(n_out).  Built once per
- * map, shared by every convolution on it.  pcc_conv_fwd_co computes the same out = act(film(bias + sum_k in[nbr] @ W[k]))
- * + residual as pcc_conv_fwd, bit for bit (same per-element MFMA chain: offsets ascending, channels ascending), with every
- * MFMA tile holding 32 list entries — full whatever the rows' neighbour masks are — and gathers that stay local.
- * w_packed from pcc_conv_pack_weights; fin, w_packed, fout, bias, film, residual 16-byte aligned; operands < 4 GiB. */
-#define PCC_COMPACT_GROUP 256
-int64_t pcc_compact_map_groups(int64_t n_out);
-int pcc_compact_map(const int32_t* nbr, int64_t n_out, int32_t K, int32_t* ent_in, uint32_t* ent_row4, uint8_t* cnt,
-                    void* stream);
-int pcc_conv_fwd_co(const float* fin, int64_t n_in, int32_t cin, const float* w_packed, const float* bias,
-                    const int32_t* ent_in, const uint32_t* ent_row4, const uint8_t* cnt, int32_t K, float* fout,
-                    int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream);
 
 /* bf16-input variant of pcc_conv_fwd (training / BASELINE config 5): features and packed weights are bf16
  * (fin [n_in, cin] bf16, cin a multiple of 64; pcc_conv_pack_weights_bf16: [K, cin/8, cout^32, 8]), products

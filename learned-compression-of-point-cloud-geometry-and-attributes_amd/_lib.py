@@ -32,23 +32,15 @@ SIGNATURES = {
     "pcc_conv_packed_elems": (c_i64, [c_i32, c_i32, c_i32]),
     "pcc_conv_pack_weights": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "pcc_order_scratch_bytes": (c_i64, [c_i64]),
-    "pcc_order_rows_by_mask": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_i64, c_void_p]),
-    "pcc_order_rows_by_mask16": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_void_p,
-                                         c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
-    "pcc_conv_fwd16": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
-                               c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+    "pcc_order_rows_by_mask": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
+    "pcc_permute_map_rows": (c_int, [c_void_p, c_void_p, c_i64, c_i32, c_void_p, c_void_p]),
     "pcc_conv_fwd": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32,
                              c_void_p, c_i64, c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
     "pcc_conv_small_max": (c_i64, [c_i64]),
     "pcc_small_map_max": (c_i64, []),
     "pcc_small_paths": (c_i32, [c_i32]),
     "pcc_small_kernel_map": (c_int, [c_void_p, c_i64, c_void_p, c_void_p, c_i64, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p,
-                                     c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_void_p]),
-    "pcc_compact_map_groups": (c_i64, [c_i64]),
-    "pcc_compact_map": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "pcc_conv_fwd_co": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i64,
-                                c_i32, c_i32, c_void_p, c_void_p, c_void_p]),
+                                     c_void_p, c_void_p, c_i64, c_void_p]),
     "pcc_conv_packed_elems_bf16": (c_i64, [c_i32, c_i32, c_i32]),
     "pcc_conv_pack_weights_bf16": (c_int, [c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p]),
     "pcc_conv_fwd_bf16": (c_int, [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_i32, c_void_p, c_i64,
@@ -105,7 +97,43 @@ def build(force=False):
     if force:
         subprocess.check_call(args + ["clean"])
     subprocess.check_call(args)
+    check_kernel_resources()
     return SO_PATH
+
+
+# kernels that must run out of registers alone: the MFMA convolutions (a spilled accumulator is a 20x slowdown, and
+# conv_small_kernel's inline-assembly LDS reads sit behind a hand-placed s_waitcnt that the compiler does not see: a spilled
+# or copied operand register would be read before its data has landed, silently)
+NO_SCRATCH_KERNELS = ("conv_small_kernel", "conv_mfma_buf_kernel", "conv_mfma_kernel")
+
+
+def check_kernel_resources(path=None):
+    """Parse the compiler's per-kernel resource remarks (csrc/Makefile writes them beside the objects) and fail loudly
+    when one of NO_SCRATCH_KERNELS uses scratch memory or spills registers.  -> {mangled kernel name: (vgprs, scratch)}"""
+    import re
+    path = path or os.path.join(_HERE, "build", "conv.resources.txt")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: the library was not built by csrc/Makefile")
+    seen, name = {}, None
+    vals = {}
+    with open(path) as f:
+        for line in f:
+            m = re.search(r"remark:\s+Function Name: (\S+)", line)
+            if m:
+                name, vals = m.group(1), {}
+                seen[name] = vals
+                continue
+            m = re.search(r"remark:\s+(VGPRs|ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill): (\d+)", line)
+            if m and name:
+                vals[m.group(1)] = int(m.group(2))
+    bad = {k: v for k, v in seen.items() if any(t in k for t in NO_SCRATCH_KERNELS)
+           and (v.get("ScratchSize [bytes/lane]", 0) or v.get("SGPRs Spill", 0) or v.get("VGPRs Spill", 0))}
+    checked = [k for k in seen if any(t in k for t in NO_SCRATCH_KERNELS)]
+    if not checked:
+        raise RuntimeError(f"{path}: no resource remarks for {NO_SCRATCH_KERNELS} (compiler flag dropped?)")
+    if bad:
+        raise RuntimeError(f"kernels with scratch memory or spills (must be none): {bad}")
+    return {k: (seen[k].get("VGPRs"), seen[k].get("ScratchSize [bytes/lane]")) for k in checked}
 
 
 def lib():

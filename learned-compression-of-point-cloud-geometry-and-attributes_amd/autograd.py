@@ -114,13 +114,12 @@ def _transposed_map(in_map, out_map, ksize, transposed):
     mask_t = torch.empty(n_in, dtype=torch.int32, device=dev)
     check(L.pcc_kernel_map_transpose(ptr(nbr), n_out, K, n_in, ptr(nbr_t), ptr(mask_t), _lib.stream()))
     order = torch.empty(n_in, dtype=torch.int32, device=dev)
-    nbr_s = torch.empty_like(nbr_t)
     gmask = torch.empty((n_in + 31) // 32, dtype=torch.int32, device=dev)
     nbytes = L.pcc_order_scratch_bytes(n_in)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    check(L.pcc_order_rows_by_mask(ptr(mask_t), ptr(in_map.coords), n_in, ORDER_BLOCK_LOG2, in_map.stride, ptr(nbr_t), K, ptr(order),
-                                   ptr(nbr_s), ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
-    res = (nbr_t, nbr_s, order, gmask)
+    check(L.pcc_order_rows_by_mask(ptr(mask_t), ptr(in_map.coords), n_in, ORDER_BLOCK_LOG2, in_map.stride, ptr(order),
+                                   ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
+    res = (nbr_t, order, gmask)
     in_map._cache[key] = (None if out_map is in_map else out_map,) + res
     return res
 
@@ -185,7 +184,7 @@ class SparseConvFn(torch.autograd.Function):
                 nbr = torch.arange(n_out, dtype=torch.int32, device=dev).unsqueeze(1).contiguous()
                 order = gmask = None
             else:
-                nbr, order, gmask, _ = in_map.ordered_kernel_map(out_map, ksize, transposed)
+                nbr, order, gmask, _ = in_map.position_ordered_table(out_map, ksize, transposed)      # the wgrad kernels index by position
             dw = torch.empty((K, cin_p, cout_p), dtype=torch.float32, device=dev)
             ne = L.pcc_conv_wgrad_scratch_elems(K, cin_p, cout_p)
             scratch = torch.empty(ne, dtype=torch.float32, device=dev)
@@ -223,9 +222,9 @@ class SparseConvFn(torch.autograd.Function):
             if ksize == 1:
                 d_feats = _launch_conv(g, wt, None, None, None, None, n_in)
             else:
-                nbr_t, nbr_s, order_t, gmask_t = _transposed_map(in_map, out_map, ksize, transposed)
+                nbr_t, order_t, gmask_t = _transposed_map(in_map, out_map, ksize, transposed)
                 if g.shape[1] % 32 == 0:
-                    d_feats = _launch_conv(g, wt, None, nbr_s, order_t, gmask_t, n_in)
+                    d_feats = _launch_conv(g, wt, None, nbr_t, order_t, gmask_t, n_in)
                 else:
                     d_feats = _launch_conv(g, wt, None, nbr_t, None, None, n_in)
         return d_feats, d_kernel, d_bias, None, None, None, None, None

@@ -32,17 +32,15 @@ struct ConvArgs {
     const float* w;       // raw [K, cin, cout] (thin path)
     const float* wp;      // packed [K, cinp/4, coutp, 4] (MFMA path)
     const float* bias;    // [cout] or null
-    const int32_t* nbr;   // [n_out, K] or null (identity); permuted by `order` on the MFMA path
+    const int32_t* nbr;   // [n_out, K] by OUTPUT ROW, or null (identity); the MFMA kernels read row order[pos] of it
     const int32_t* order;   // [n_out] execution position -> output row, or null (natural order)
     const uint32_t* gmask;  // [ceil(n_out/32)] offsets live per 32 positions, or null (all live)
-    const uint32_t* gmask16;  // [ceil(n_out/16)] offsets live per 16 positions: the 16-row-tile kernels (M16), else null
     float* fout;
     const float* film;      // [n_out, 2*cout] or null
     const float* residual;  // [n_out, cout] or null
     int64_t n_in, n_out;
     int cin, cout, coutp, K, act;
     int bf16;    // buffer kernel: fin / wp hold bf16 (pcc_conv_fwd_bf16); accumulation and output stay fp32
-    int debug;   // development ablations of conv_mfma_kernel, compiled in only with -DPCC_CONV_ABLATE (PCC_CONV_DEBUG): 1 no DMA, 4 no barrier, 8 no MFMA, 16 no A DMA, 32 no W DMA
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -125,12 +123,6 @@ __global__ __launch_bounds__(256) void pack_weights_x3_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------
 // MFMA path
 // ---------------------------------------------------------------------------------------------
-// The ablation switches cost ~3 % when compiled in (branches split the scheduling regions of the main loop)
-#ifdef PCC_CONV_ABLATE
-#define DBG(a) ((a).debug)
-#else
-#define DBG(a) 0
-#endif
 constexpr int A_LD_DMA = 32;   // LDS-DMA image: unpadded 128-B rows, 16-B slots XOR-swizzled by (row >> 1) & 7
 
 template <int BM, int BN, bool X3 = false>
@@ -222,7 +214,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
         const int64_t pos = row0 + grow[i];
         rvalid[i] = pos < a.n_out;
         const int64_t ps = rvalid[i] ? pos : a.n_out - 1;
-        nbr_row[i] = HAS_NBR ? a.nbr + ps * K : nullptr;
+        nbr_row[i] = HAS_NBR ? a.nbr + (a.order ? (int64_t)a.order[ps] : ps) * K : nullptr;
         idx_cur[i] = idx_nxt[i] = (int)ps;          // identity map when nbr == NULL (kernel_size 1)
     }
 
@@ -255,14 +247,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wid);               // provably wave-uniform LDS bases
     auto dma_step = [&](int k, int c, int buf) {
-        if (!(DBG(a) & 16)) {
+        {
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             float* dst = As + buf * A_ELEMS + (wave_u * RPT + i) * 256;   // + lane * 16 B added by the hardware
             __builtin_amdgcn_global_load_lds((gbl_ptr_t)(a_src[i] + c * 32), (lds_ptr_t)dst, 16, 0, 0);
         }
         }
-        if (DBG(a) & 32) return;
         const float* wbase = a.wp + ((int64_t)k * (a.cin / 4) + c * 8) * a.coutp * 4;     // scalar
 #pragma unroll
         for (int j = 0; j < W_LOADS; ++j) {
@@ -358,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
                 for (int i = 0; i < RPT; ++i) idx_cur[i] = idx_nxt[i];     // values that arrived >= one step ago
                 set_a_src(idx_cur);
             }
-            if (has_next && !(DBG(a) & 1)) {
+            if (has_next) {
                 // buffer cur^1 was last read in the previous step, which every wave has left (barrier)
                 dma_step(nk, nc, cur ^ 1);
             }
@@ -367,8 +358,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvArgs a) {
             int kn2 = knext;
             if (advance) { rem2 &= rem2 - 1u; kn2 = rem2 ? __builtin_ctz(rem2) : -1; }
             load_idx(kn2 >= 0 ? kn2 : k, idx_nxt);
-            if (!(DBG(a) & 8)) compute(cur, k);
-            if (!(DBG(a) & 4)) __syncthreads();     // vmcnt(0) + lgkmcnt(0) + barrier: next image complete
+            compute(cur, k);
+            __syncthreads();     // vmcnt(0) + lgkmcnt(0) + barrier: next image complete
             if (!has_next) break;
             if (advance) { k = nk; rem = rem2; knext = kn2; }
             c = nc;
@@ -437,18 +428,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // leading one — lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, in that fixed order — go through v_mfma_f32_32x32x16_bf16
 // with fp32 accumulation: 12 MFMAs of 8 passes per 32 x 32 x 32 block instead of 16 of 16 (3/8 of the matrix-pipe time),
 // every bf16 product exact in fp32, the dropped terms below 3 x 2^-24 of |x||w| — the size of an fp32 rounding.
-// M16 (fp32 only, pcc_conv_fwd16): the MFMA tiles are 16 rows x 16 columns (v_mfma_f32_16x16x4_f32) instead of 32 x 32
-// (v_mfma_f32_32x32x2_f32), and a 16-ROW half of a wave's rows skips the offsets none of its rows has (group masks per 16
-// positions).  One 16x16x4 contracts four channels in the order two chained 32x32x2 do — lane group kq = lane >> 4 supplies
-// channel 8 kk + 4 (kq & 1) + 2 p + (kq >> 1) of sub-block kk for p = 0, 1 — and the hardware's chain is the same fused
-// multiply-add sequence either way (tools/micro/mfma_shapes_bitwise.hip: 0 of 5.1 M elements differ), so an element's
-// result is bit-identical to the 32-row kernels'.  Same throughput per FLOP (32 cycles per 2048 FLOP); what it buys is
-// fill on mask-diverse sets: issued / useful 1.80 -> 1.60 on the sparse sets an untrained decoder keeps, 1.08 -> 1.04 on
-// surfaces (tools/order_experiment.py); what it costs is twice the LDS fragment reads (8 bytes per lane instead of 16).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false, bool M16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)           // the buffer builtins exist in the device pass only; the host pass needs just the stub
-    static_assert(!M16 || (!BF16 && !X3), "16-row tiles exist for the fp32 kernel only");
     constexpr int RPT = BM / 32;              // gather DMAs per thread and step (8 lanes per row)
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int MT = WM / 32, NT = WN / 32;
@@ -478,7 +460,6 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
     const int K = a.K;
 
     uint32_t tmask, mmask[MT];
-    [[maybe_unused]] uint32_t hmask[MT][2];          // M16: offsets live per 16-row half of my 32-row tiles
     {
         const uint32_t all = (K >= 32) ? 0xffffffffu : ((1u << K) - 1u);
         if (a.gmask) {
@@ -492,42 +473,22 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
                 const int64_t g = g0 + (wrow >> 5) + m;
                 const uint32_t v = (g < ng) ? (a.gmask[g] & all) : 0u;
                 mmask[m] = __builtin_amdgcn_readfirstlane(v);
-                if constexpr (M16) {
-                    const int64_t ng16 = (a.n_out + 15) >> 4;
-#pragma unroll
-                    for (int hm = 0; hm < 2; ++hm) {
-                        const int64_t g16 = 2 * g + hm;
-                        const uint32_t v16 = (a.gmask16 && g16 < ng16) ? (a.gmask16[g16] & all) : (a.gmask16 ? 0u : v);
-                        hmask[m][hm] = __builtin_amdgcn_readfirstlane(v16);
-                    }
-                }
             }
         } else {
             tmask = all;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                mmask[m] = all;
-                if constexpr (M16) hmask[m][0] = hmask[m][1] = all;
-            }
+            for (int m = 0; m < MT; ++m) mmask[m] = all;
         }
         tmask = __builtin_amdgcn_readfirstlane(tmask);
     }
 
-    [[maybe_unused]] f32x16 acc[MT][NT];
-    // M16: the same 16 registers per 32 x 32 block, as four 16 x 16 blocks (half hm, column half cb) of 4 registers:
-    // acc16[m][hm][n][cb][reg] = D[row 16 hm + 4 (lane >> 4) + reg][column 16 cb + (lane & 15)]
-    [[maybe_unused]] f32x4 acc16[MT][2][NT][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            if constexpr (M16) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc16[m][q >> 1][n][q & 1] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
-            }
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
         }
 
     if (tmask != 0u) {
@@ -551,7 +512,7 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             rvalid[i] = pos < a.n_out;
             const int64_t ps = rvalid[i] ? pos : a.n_out - 1;
             q16[i] = (uint32_t)((gchunk ^ ((grow >> 1) & 7)) * 16);     // global chunk held by my LDS slot
-            n_voff[i] = (uint32_t)(ps * K * 4);
+            n_voff[i] = (uint32_t)(((HAS_NBR && a.order) ? (int64_t)a.order[ps] : ps) * K * 4);      // the table is by output row
             idx_nxt[i] = (int)ps;                                        // identity map when nbr == NULL
         }
         uint32_t w_voff[W_LOADS];
@@ -716,74 +677,8 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             }
             __builtin_amdgcn_s_setprio(0);
         };
-        // M16 fragments.  Lane (j = lane & 15, kq = lane >> 4) reads, for sub-block kk, the floats 0 / 2 (kq < 2) or 1 / 3
-        // (kq >= 2) of the 16-B chunk 2 kk + (kq & 1) — of row 16 hm + j of a 32-row tile, and of weight column 16 cb + j of a
-        // 32-column tile: one ds_read2_b32 per operand block and sub-block, no selects.
-        [[maybe_unused]] uint32_t a16_addr[2][4], w16_addr[2];
-        if constexpr (M16) {
-            const int j16 = lane & 15, kq = lane >> 4;
-            const int R = wrow + j16;                      // + 16 hm + 32 m, which leave the swizzle (R >> 1) & 7 unchanged
-            const int sw16 = (R >> 1) & 7;
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk)
-                    a16_addr[b][kk] = (uint32_t)((b * A_ELEMS + R * 32 + (((2 * kk + (kq & 1)) ^ sw16) * 4) + (kq >> 1)) * 4);
-                w16_addr[b] = (uint32_t)((2 * A_ELEMS + b * W_ELEMS + ((kq & 1) * BN + wcol + j16) * 4 + (kq >> 1)) * 4);
-            }
-        }
-        auto a16_at = [&](uint32_t base, int m, int hm) -> uint32_t { return base + (uint32_t)((16 * hm + 32 * m) * 32 * 4); };
-        auto lds2 = [&](uint32_t addr) {                                     // floats at addr and addr + 8
-            const float* q = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + addr);
-            return f32x2{q[0], q[2]};
-        };
-        // One 32-row tile m of the wave at a time; LIVE: bit hm = its 16-row half hm takes this offset (three straight-line
-        // variants per tile; all 15 combinations of a two-tile wave in one block overflowed the compiler's register promotion)
-        auto compute_live16 = [&](auto bufc, auto mc, auto live_tag) {
-            constexpr int buf = decltype(bufc)::value;
-            constexpr int m = decltype(mc)::value;
-            constexpr unsigned LIVE = decltype(live_tag)::value;
-            f32x2 av[2][2], bv[2][NT][2];
-            __builtin_amdgcn_s_setprio(1);
-            auto load = [&](int slot, int kk) {
-#pragma unroll
-                for (int hm = 0; hm < 2; ++hm)
-                    if ((LIVE >> hm) & 1u) av[slot][hm] = lds2(a16_at(a16_addr[buf][kk], m, hm));
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int cb = 0; cb < 2; ++cb)
-                        bv[slot][n][cb] = lds2(w16_addr[buf] + (uint32_t)((2 * kk * BN + 32 * n + 16 * cb) * 16));
-            };
-            load(0, 0);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int cbf = kk & 1, nb = cbf ^ 1;
-                if (kk + 1 < 4) load(nb, kk + 1);
-#pragma unroll
-                for (int p = 0; p < 2; ++p)
-#pragma unroll
-                    for (int hm = 0; hm < 2; ++hm)
-#pragma unroll
-                        for (int n = 0; n < NT; ++n)
-#pragma unroll
-                            for (int cb = 0; cb < 2; ++cb)
-                                if ((LIVE >> hm) & 1u)
-                                    acc16[m][hm][n][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cbf][hm][p], bv[cbf][n][cb][p],
-                                                                                               acc16[m][hm][n][cb], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-        };
-        auto compute16_tile = [&](auto bufc, auto mc, unsigned lv) {
-            if (lv == 3u) compute_live16(bufc, mc, std::integral_constant<unsigned, 3u>{});
-            else if (lv == 1u) compute_live16(bufc, mc, std::integral_constant<unsigned, 1u>{});
-            else if (lv == 2u) compute_live16(bufc, mc, std::integral_constant<unsigned, 2u>{});
-        };
         auto compute = [&](auto bufc, unsigned live) {        // live: wave-uniform, bit m = 32-row tile m has this offset
-            if constexpr (M16) {                              // here: bit 2 m + hm = 16-row half hm of tile m
-                compute16_tile(bufc, std::integral_constant<int, 0>{}, live & 3u);
-                if constexpr (MT == 2) compute16_tile(bufc, std::integral_constant<int, 1>{}, (live >> 2) & 3u);
-            } else if constexpr (MT == 1) {
+            if constexpr (MT == 1) {
                 if (live) compute_live(bufc, std::integral_constant<unsigned, 1u>{});
             } else {
                 if (live == 3u) compute_live(bufc, std::integral_constant<unsigned, 3u>{});
@@ -807,10 +702,7 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
             const int kn2 = rem2 ? __builtin_ctz(rem2) : (knext >= 0 ? knext : k);
             unsigned live = 0;
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                if constexpr (M16) live |= (((hmask[m][0] >> k) & 1u) | (((hmask[m][1] >> k) & 1u) << 1)) << (2 * m);
-                else live |= ((mmask[m] >> k) & 1u) << m;
-            }
+            for (int m = 0; m < MT; ++m) live |= ((mmask[m] >> k) & 1u) << m;
             static_for<0, CCH>([&](auto cc) {
                 constexpr int c = decltype(cc)::value;
                 constexpr int buf = (P + c) & 1;
@@ -844,21 +736,19 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
     }
 
     // epilogue: D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r] per 32x32 tile
-    // (M16: register 4 (2 hm + cb) + e = D[row 16 hm + 4 (lane >> 4) + e][col 16 cb + (lane & 15)])
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int col = nt * BN + wcol + 32 * n + (M16 ? 16 * ((reg >> 2) & 1) + (lane & 15) : r);
+                const int col = nt * BN + wcol + 32 * n + r;
                 if (col >= a.cout) continue;
                 const float bcol = a.bias ? a.bias[col] : 0.0f;
-                const int64_t pos = row0 + wrow + 32 * m + (M16 ? 16 * (reg >> 3) + 4 * (lane >> 4) + (reg & 3)
-                                                                : (reg & 3) + 8 * (reg >> 2) + 4 * h);
+                const int64_t pos = row0 + wrow + 32 * m + (reg & 3) + 8 * (reg >> 2) + 4 * h;
                 if (pos >= a.n_out) continue;
                 const int64_t row = a.order ? a.order[pos] : pos;
-                float v = (M16 ? acc16[m][reg >> 3][n][(reg >> 2) & 1][reg & 3] : acc[m][n][reg]) + bcol;
+                float v = acc[m][n][reg] + bcol;
                 if (a.film) {
                     const float* fr = a.film + row * (2 * (int64_t)a.cout);
                     v = v * fr[col] + fr[a.cout + col];
@@ -878,7 +768,8 @@ __global__ __launch_bounds__(256) void conv_mfma_buf_kernel(const ConvArgs a) {
 // serial chain of one wave's MFMAs: a 32 x 32 tile over K x cin contraction steps of v_mfma_f32_32x32x2_f32 (64 cycles per
 // two channels) = 46 us for 27 x 128 channels at the peak clock, whatever the row count (measured: 66 us).  Here
 //   * a wave owns ONE 16 x 16 block (v_mfma_f32_16x16x4_f32: 32 cycles per four channels, issued back to back on one
-//     accumulator — tools/micro/mfma_chain_latency.hip — and the same fused multiply-add chain bit for bit, see M16 above),
+//     accumulator — tools/micro/mfma_chain_latency.hip — and the same fused multiply-add chain bit for bit as two chained
+//     v_mfma_f32_32x32x2_f32: tools/micro/mfma_shapes_bitwise.hip, 0 of 5.1 M elements differ),
 //     a workgroup 32 rows x 32 columns: four times the workgroups, every chain a quarter as long (12 us);
 //   * nothing but the chain runs in the MFMA waves' instruction stream.  The fp32 MFMA shares its SIMD with the vector ALU
 //     (any vector instruction between two MFMAs costs its issue time plus ~14 cycles, unhidden) and an LDS-DMA costs its
@@ -925,8 +816,9 @@ __global__ __launch_bounds__(512) void conv_small_kernel(const ConvArgs a) {
 
     if (tmask != 0u) {
         for (int e = t; e < 32 * K; e += 512) {
-            const int64_t pos = row0 + e / K;
-            idx_s[e] = pos < a.n_out ? a.nbr[row0 * K + e] : -1;
+            const int lr = e / K;
+            const int64_t pos = row0 + lr;
+            idx_s[e] = pos < a.n_out ? a.nbr[(a.order ? (int64_t)a.order[pos] : pos) * K + (e - lr * K)] : -1;
         }
         __syncthreads();
     }
@@ -1283,9 +1175,7 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool HAS_NBR>
 static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
     auto kern = conv_mfma_kernel<BM, BN, WAVES_M, WAVES_N, HAS_NBR>;
-    static int extra_lds = -1;      // development knob: PCC_CONV_EXTRA_LDS=<bytes> lowers workgroups per CU
-    if (extra_lds < 0) { const char* e = getenv("PCC_CONV_EXTRA_LDS"); extra_lds = e ? atoi(e) : 0; }
-    const int lds = conv_lds_bytes<BM, BN>() + extra_lds;
+    const int lds = conv_lds_bytes<BM, BN>();
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
@@ -1298,10 +1188,10 @@ static int launch_mfma_impl(const ConvArgs& a, hipStream_t st) {
     return PCC_OK;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false, bool M16 = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int CCH, bool HAS_NBR, bool BF16 = false, bool X3 = false>
 static int launch_mfma_buf_impl(const ConvArgs& a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16, X3, M16>;
+    auto kern = conv_mfma_buf_kernel<BM, BN, WAVES_M, WAVES_N, CCH, HAS_NBR, BF16, X3>;
     const int lds = conv_lds_bytes<BM, BN, X3>();
     if (!attr_set) {
         PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -1348,7 +1238,6 @@ static int launch_small_impl(const ConvArgs& a, hipStream_t st) {
 // Measured on MI355X (tools/conv_small_bench.py, one launch): 128 -> 128 on 56 .. 1,136 rows 27 us against 66, 64 -> 64
 // 16.5 against 72, 64 -> 128 17 against 38; even at 616 tiles (4,904 rows x 128 columns: 59 against 66; 19,256 rows x 64
 // columns = 1,204 tiles: 62 against 74), behind from 1,000 tiles on (8,000 rows x 128: 90 against 66).
-// PCC_CONV_SMALL_CFG=<chunks per step><stages> forces one pipeline shape (A/B).
 static int64_t g_small_max = -1;
 static int64_t small_max_value() {
     if (g_small_max < 0) { const char* e = getenv("PCC_CONV_SMALL_MAX"); g_small_max = e ? atoll(e) : 640; }
@@ -1360,16 +1249,7 @@ static bool small_launch(const ConvArgs& a) {
 }
 
 static int launch_small(const ConvArgs& a, hipStream_t st) {
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("PCC_CONV_SMALL_CFG"); cfg = e ? atoi(e) : 0; }
     const int cch = a.cin / 32;
-    switch (cfg) {
-        case 18: return launch_small_impl<1, 8>(a, st);
-        case 23: if (cch % 2 == 0) return launch_small_impl<2, 3>(a, st); break;
-        case 24: if (cch % 2 == 0) return launch_small_impl<2, 4>(a, st); break;
-        case 43: if (cch % 4 == 0) return launch_small_impl<4, 3>(a, st); break;
-        default: break;
-    }
     // a step of four chunks (27 barriers for 128 channels instead of 54) while one workgroup per CU — 100 KB of LDS — holds
     // the launch; else two chunks per step at 52 KB (three workgroups per CU); odd chunk counts one chunk per step
     const int64_t wgs = ((a.n_out + 31) / 32) * (a.coutp / 32);
@@ -1380,20 +1260,6 @@ static int launch_small(const ConvArgs& a, hipStream_t st) {
 template <int BM, int BN, int WAVES_M, int WAVES_N>
 static int launch_mfma(const ConvArgs& a, hipStream_t st) {
     const int path = conv_path();
-    // 16-row MFMA tiles (pcc_conv_fwd16: a.gmask16 set): instantiated for the channel counts the codec has, maps only.  Waves
-    // that own two 32-row tiles (128-row workgroups) take them up to 64 input channels: with four or six channel chunks of
-    // straight-line steps x two tiles x three liveness variants the compiler stops promoting the accumulators to registers
-    // (240-368 bytes of scratch per lane, 20x slower) — those launches keep the 32-row kernels, bit-identical.
-    constexpr bool TWO_TILES = (BM / WAVES_M) == 64;
-    if (path == 0 && a.gmask16 && a.nbr && fits_buffer_path(a)) {
-        switch (a.cin / 32) {
-            case 1: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 1, true, false, false, true>(a, st);
-            case 2: return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 2, true, false, false, true>(a, st);
-            case 4: if constexpr (!TWO_TILES) return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 4, true, false, false, true>(a, st); else break;
-            case 6: if constexpr (!TWO_TILES) return launch_mfma_buf_impl<BM, BN, WAVES_M, WAVES_N, 6, true, false, false, true>(a, st); else break;
-            default: break;          // other widths: the 32-row kernels below (bit-identical)
-        }
-    }
     if (path == 0 && fits_buffer_path(a)) {
 #define PCC_BUF_CASE(C)                                                                                        \
     case C:                                                                                                    \
@@ -1506,9 +1372,8 @@ int pcc_conv_fwd_bf16(const uint16_t* fin, int64_t n_in, int32_t cin, const uint
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
     a.fin = reinterpret_cast<const float*>(fin); a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
-    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.gmask16 = nullptr; a.fout = fout; a.film = film; a.residual = residual;
+    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout; a.film = film; a.residual = residual;
     a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 1;
-    a.debug = 0;
     PCC_REQUIRE((uint64_t)n_in * cin * 2 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB,
                 "pcc_conv_fwd_bf16: operands of 4 GiB and more are not supported");
     hipStream_t st = as_stream(stream);
@@ -1546,9 +1411,8 @@ int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t*
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
     a.fin = fin; a.w = nullptr; a.wp = reinterpret_cast<const float*>(w_packed); a.bias = bias;
-    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.gmask16 = nullptr; a.fout = fout; a.film = film; a.residual = residual;
+    a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout; a.film = film; a.residual = residual;
     a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout; a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 0;
-    a.debug = 0;
     PCC_REQUIRE((uint64_t)n_in * cin * 4 <= BUF_OOB && (uint64_t)n_out * K * 4 <= BUF_OOB && (uint64_t)K * cin * a.coutp * 6 <= BUF_OOB,
                 "pcc_conv_fwd_x3: operands of 4 GiB and more are not supported");
     hipStream_t st = as_stream(stream);
@@ -1556,13 +1420,10 @@ int pcc_conv_fwd_x3(const float* fin, int64_t n_in, int32_t cin, const uint16_t*
     // occupancy decides — the three-plane weight slab makes a 64 x 128 tile 64 KB of LDS (two workgroups per CU) and a
     // 64 x 64 tile 40 KB (four).  64-wide outputs: 64 x 64 tiles 5.2 ms against 5.75 for 128 x 64 on the 5.16 M-row layers;
     // 128-wide outputs: 64 x 128 tiles 4.95-5.15 ms against 5.2-5.35 for 64 x 64 (which gathers every row twice).
-    // PCC_X3_TILE=64 | 128 forces 64 x 64 / the wider shapes for A/B runs.
-    static int tile = -1;
-    if (tile < 0) { const char* e = getenv("PCC_X3_TILE"); tile = e ? atoi(e) : 0; }
     const int64_t wgs128 = ((a.n_out + 63) / 64) * (a.coutp / 128);
-    if (a.coutp % 128 == 0 && (wgs128 < 768 || tile == 64)) return launch_mfma_x3<64, 64, 2, 2>(a, st);
+    if (a.coutp % 128 == 0 && wgs128 < 768) return launch_mfma_x3<64, 64, 2, 2>(a, st);
     if (a.coutp % 128 == 0) return launch_mfma_x3<64, 128, 2, 2>(a, st);
-    if (a.coutp % 64 == 0) return tile == 128 ? launch_mfma_x3<128, 64, 2, 2>(a, st) : launch_mfma_x3<64, 64, 2, 2>(a, st);
+    if (a.coutp % 64 == 0) return launch_mfma_x3<64, 64, 2, 2>(a, st);
     pcc::set_error("pcc_conv_fwd_x3: cout=%d not supported (output width rounded up to 32 must be a multiple of 64)", cout);
     return PCC_ERR_UNSUPPORTED;
 }
@@ -1610,23 +1471,15 @@ int64_t pcc_conv_small_max(int64_t workgroups) {
 int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
                  const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, int32_t K, float* fout,
                  int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
-    return pcc_conv_fwd16(fin, n_in, cin, w, w_packed, bias, nbr, order, group_mask32, nullptr, K, fout, n_out, cout, act, film, residual,
-                          stream);
-}
-
-int pcc_conv_fwd16(const float* fin, int64_t n_in, int32_t cin, const float* w, const float* w_packed, const float* bias,
-                   const int32_t* nbr, const int32_t* order, const uint32_t* group_mask32, const uint32_t* group_mask16, int32_t K,
-                   float* fout, int64_t n_out, int32_t cout, int32_t act, const float* film, const float* residual, void* stream) {
     PCC_REQUIRE(K >= 1 && K <= 27, "pcc_conv_fwd: K=%d out of range", K);
     PCC_REQUIRE(cin % 32 != 0 || cin <= 256, "pcc_conv_fwd: MFMA path supports cin <= 256 (got %d)", cin);
     PCC_REQUIRE(nbr != nullptr || (K == 1 && n_in == n_out), "pcc_conv_fwd: nbr == NULL needs K == 1 and n_in == n_out");
     PCC_REQUIRE(act >= 0 && act <= 2, "pcc_conv_fwd: bad activation %d", act);
     if (n_out <= 0) return PCC_OK;
     ConvArgs a;
-    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.gmask16 = group_mask16; a.fout = fout;
+    a.fin = fin; a.w = w; a.wp = w_packed; a.bias = bias; a.nbr = nbr; a.order = order; a.gmask = group_mask32; a.fout = fout;
     a.film = film; a.residual = residual; a.n_in = n_in; a.n_out = n_out; a.cin = cin; a.cout = cout;
     a.coutp = round_up32(cout); a.K = K; a.act = act; a.bf16 = 0;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("PCC_CONV_DEBUG"); dbg = e ? atoi(e) : 0; } a.debug = dbg; }
     hipStream_t st = as_stream(stream);
     if (cin % 32 == 0) {
         PCC_REQUIRE(w_packed != nullptr, "pcc_conv_fwd: MFMA path (cin=%d) needs packed weights", cin);

@@ -194,146 +194,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #endif
 }
 
-// Blocks of at most 64 x 64 (the 64-channel layers: 8 k FLOP per gathered (X row, dY row) pair of 512 B) are bound by
-// their gathers, not by the MFMA pipe, so the tiling is chosen for bytes: a workgroup owns FOUR kernel offsets — one per
-// wave, each wave holding its offset's whole 64 x 64 accumulator — and every SPLIT-th group of 32 output rows.  The
-// group's dY rows are staged once and shared by the four waves; wave w gathers the X rows of its own offset.  Bytes per
-// four pairs: 4 x 256 + 256 instead of 4 x 512 (the one-offset kernel above re-reads every dY row once per offset).
-// LDS images as above, [chunk][row][32]; single-buffered (40 KB: four workgroups per CU hide the round trips).
-// Groups in which none of the four offsets occurs are skipped 64 masks at a time; a wave whose offset is absent from
-// a visited group neither gathers nor multiplies.
-__global__ __launch_bounds__(256) void conv_wgrad_quad_kernel(const WgradArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                 // [4 waves][2 chunks][32 rows][32 ch]
-    float* Ys = smem + 4 * 2048;      // [2 chunks][32 rows][32 co]
-    const int t = threadIdx.x, lane = t & 63, wid = t >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wid);
-    const int SPLIT = a.split;
-    const int set = blockIdx.x / SPLIT, s = blockIdx.x % SPLIT;
-    const int kslot = 4 * set + wave_u;
-    const bool has_k = kslot < a.K;
-    const int k = has_k ? wgrad_offset_of(kslot, a.K) : 0;
-    uint32_t set_mask = 0u;
-#pragma unroll
-    for (int w = 0; w < 4; ++w)
-        if (4 * set + w < a.K) set_mask |= 1u << wgrad_offset_of(4 * set + w, a.K);
-    const int cbi = a.cin / 32, cbo = a.cout / 32;          // 1 or 2 chunks each
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.0f;
-
-    __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.fin), 0, (int)(uint32_t)(a.n_in * a.cin * 4), WG_FLAGS);
-    __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)(uint32_t)(a.n_out * a.cout * 4), WG_FLAGS);
-    const int64_t ng = (a.n_out + 31) >> 5;
-    const int slot = lane & 7, rsub = lane >> 3;            // DMA role: 8 lanes per 128-B chunk row, 8 rows per instruction
-
-    int64_t gb = (int64_t)s - 64 * (int64_t)SPLIT;
-    unsigned long long live = 0ull;
-    uint32_t gml = 0u;
-    uint32_t gm_cur = 0u;
-    auto pop = [&]() -> int64_t {                           // next of my groups that holds one of the set's offsets, or -1
-        while (!live) {
-            gb += 64 * (int64_t)SPLIT;
-            if (gb >= ng) return -1;
-            const int64_t gmine = gb + (int64_t)lane * SPLIT;
-            gml = (gmine < ng) ? (a.gmask ? a.gmask[gmine] : 0xffffffffu) : 0u;
-            live = __ballot((gml & set_mask) != 0u);
-        }
-        const int bit = __ffsll(live) - 1;
-        live &= live - 1;
-        gm_cur = (uint32_t)__shfl((int)gml, bit, 64);
-        return gb + (int64_t)bit * SPLIT;
-    };
-    // indices / row ids of the next group are fetched one iteration ahead, beside the current group's gathers
-    int idx[4];
-    int64_t yrow;
-    bool yok;
-    bool mine;                                               // my offset occurs in the group
-    auto load_rows = [&](int64_t g, uint32_t gm) {
-        mine = g >= 0 && has_k && ((gm >> k) & 1u);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t pos = g * 32 + 8 * i + rsub;
-            idx[i] = (mine && pos < a.n_out) ? a.nbr[pos * a.K + k] : -1;
-        }
-        const int64_t ypos = g * 32 + 8 * wave_u + rsub;     // wave w stages dY rows 8 w .. 8 w + 7 of the group
-        yok = g >= 0 && ypos < a.n_out;
-        yrow = yok ? (a.order ? a.order[ypos] : ypos) : 0;
-    };
-    int64_t g = pop();
-    load_rows(g, gm_cur);
-    while (g >= 0) {
-        const bool cur_mine = mine;
-        if (cur_mine) {
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                if (c >= cbi) break;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t vo = (idx[i] >= 0) ? (uint32_t)idx[i] * (uint32_t)(a.cin * 4) + (uint32_t)(c * 128 + slot * 16) : WG_OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (lds_ptr_t)(Xs + wave_u * 2048 + c * 1024 + i * 256), 16, vo, 0, 0, 0);
-                }
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            if (c >= cbo) break;
-            const uint32_t vo = yok ? (uint32_t)yrow * (uint32_t)(a.cout * 4) + (uint32_t)(c * 128 + slot * 16) : WG_OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (lds_ptr_t)(Ys + c * 1024 + wave_u * 256), 16, vo, 0, 0, 0);
-        }
-        g = pop();
-        load_rows(g, gm_cur);
-        __syncthreads();
-        if (cur_mine) {
-            const float* Ab = Xs + wave_u * 2048 + h * 32 + r;
-            const float* Bb = Ys + h * 32 + r;
-#pragma unroll 4
-            for (int kp = 0; kp < 16; ++kp) {
-                float av[2], bv[2];
-#pragma unroll
-                for (int m = 0; m < 2; ++m) av[m] = (m < cbi) ? Ab[m * 1024 + kp * 64] : 0.0f;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) bv[n] = (n < cbo) ? Bb[n * 1024 + kp * 64] : 0.0f;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        if (m < cbi && n < cbo) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[n], acc[m][n], 0, 0, 0);
-            }
-        }
-        __syncthreads();
-    }
-
-    if (!has_k) return;
-    float* P = a.partial + ((int64_t)s * a.K + k) * a.cin * a.cout;
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (m >= cbi) continue;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            if (n >= cbo) continue;
-            const int co = n * 32 + r;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int ci = m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                P[(int64_t)ci * a.cout + co] = acc[m][n][reg];
-            }
-        }
-    }
-#endif
-}
-
 // Slice kernel for the 64-channel class (the default for K = 27): what bounds these shapes is the byte rate of their
 // gathers — every (X row, dY row) pair is 512 B for 8 k FLOP, twice the forward convolution's bytes per FLOP, and the
 // measured rates (47-57 TFLOP/s) are the forward kernel's gather rate divided by two — so the tiling is chosen to move
-// fewer bytes WITHOUT idling waves (the quad kernel above moved fewer bytes and idled them):
+// fewer bytes WITHOUT idling waves (round 2's four-offsets-per-workgroup kernel, one offset per wave, moved fewer bytes
+// and idled the waves whose offset a group lacks: same time; removed in round 4):
 //   * a workgroup owns the nine offsets of one dz plane and every SPLIT-th group of 32 output rows; the group's dY rows are
 //     staged ONCE and reused by every offset of the plane that occurs in the group (about four of nine on a surface):
 //     8 + 8 L KB per L offset-steps instead of 16 L;
@@ -873,16 +738,6 @@ static inline int wgrad_splits(int64_t n_out) {            // at least ~48 row g
     const int64_t want = ((n_out + 31) / 32) / 48;
     return (int)(want < 8 ? 8 : (want > WG_SPLIT_MAX ? WG_SPLIT_MAX : want));
 }
-// quad kernel (four offsets per workgroup): 64-channel-class blocks of a 27-offset kernel; PCC_WGRAD_QUAD=0 keeps the
-// one-offset kernel for A/B runs
-static inline bool wgrad_quad(int cin, int cout, int K) {
-    // opt-in (PCC_WGRAD_QUAD=1): measured on MI355X it moves 25 % fewer bytes than the one-offset kernel and takes the
-    // same time (850 k-row shell 64 -> 64: 49.8 vs 57.2 TFLOP/s; 265 k rows: 54.9 vs 48.3) — the loop is bound by the
-    // round trips between its barriers, not by gather bytes
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("PCC_WGRAD_QUAD"); on = (e && e[0] == '1') ? 1 : 0; }
-    return on && wgrad_rowsplit(cin, cout) && K == 27;
-}
 // slice kernel (nine offsets = one dz plane per workgroup, dY rows staged once per group): the default for 64-channel-class
 // blocks of a 27-offset kernel; PCC_WGRAD_SLICE=0 keeps the one-offset kernel for A/B runs
 static inline bool wgrad_slice(int cin, int cout, int K) {
@@ -897,7 +752,7 @@ static inline int wgrad_slice_splits(int64_t n_out) {      // three workgroup se
 }
 static inline int wgrad_partials(int cin, int cout, int split, int K) {
     if (!wgrad_mfma(cin, cout)) return WG_SPLIT_THIN;
-    if (wgrad_slice(cin, cout, K) || wgrad_quad(cin, cout, K)) return split;
+    if (wgrad_slice(cin, cout, K)) return split;
     return split * (wgrad_rowsplit(cin, cout) ? 4 : 1);
 }
 
@@ -943,8 +798,6 @@ int pcc_conv_wgrad(const float* fin, int64_t n_in, int32_t cin, const float* dy,
             else if (O == 9) PCC_SLICE(9);
             else PCC_SLICE(5);
 #undef PCC_SLICE
-        } else if (wgrad_quad(cin, cout, K)) {
-            hipLaunchKernelGGL(conv_wgrad_quad_kernel, dim3((unsigned)(((K + 3) / 4) * a.split)), dim3(256), 10 * 1024 * sizeof(float), st, a);
         } else {
             const dim3 grid((unsigned)(K * a.split), (unsigned)((cin + 127) / 128), (unsigned)((cout + 127) / 128));
             hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 8 * 1024 * sizeof(float), st, a);

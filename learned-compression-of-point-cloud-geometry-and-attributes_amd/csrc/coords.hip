@@ -729,18 +729,13 @@ int pcc_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_
     // the input set's grid: pitch `step` for a (strided) convolution, 2 * step for a transposed one
     const int in_stride = sign > 0 ? step : 2 * step;
     const int pitch = sign > 0 ? 0 : 2 * step;
-    static int variant = -1;      // PCC_KMAP_VARIANT=generic: A/B switch; default = offset-fastest, K = 27.  (A wave-per-(dx, dy)-column
-    if (variant < 0) {            // variant measured 2.0 ms against 1.35 ms on the 5.16 M-row set — a wave instruction touched 64
-        const char* e = getenv("PCC_KMAP_VARIANT");      // different lines instead of ~25 — and was removed in round 3.)
-        variant = !e ? 0 : (e[0] == 'g' ? 1 : 0);
-    }
     const bool pow2 = pitch == 0 || (pitch & (pitch - 1)) == 0;
     unsigned long long* pc = reinterpret_cast<unsigned long long*>(pair_count);
     const uint64_t tmask = (uint64_t)(in_cap - 1);
     const int tshift = grid_shift_of(in_stride);
     const unsigned nb = blocks_for(n_out, 64);
     hipStream_t st = as_stream(stream);
-    if (ksize == 3 && variant == 0) {
+    if (ksize == 3) {      // offset-fastest lanes, K = 27 at compile time; kernel sizes 1 and 2 take the generic kernel
         if (pow2) hipLaunchKernelGGL(kernel_map27_kernel<true>, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,
                                      sign * step, pitch, nbr, row_mask, pc);
         else hipLaunchKernelGGL(kernel_map27_kernel<false>, dim3(nb), dim3(256), 0, st, out_coords, n_out, in_keys, in_vals, tmask, tshift,

@@ -274,14 +274,13 @@ __device__ __forceinline__ uint32_t order_key_of(uint32_t m, const int* pos_s) {
 }
 
 __global__ __launch_bounds__(256) void order_keys32_kernel(const uint32_t* __restrict__ row_mask, int64_t n,
-                                                           const uint32_t* __restrict__ counts, uint32_t* __restrict__ keys,
-                                                           int legacy) {
+                                                           const uint32_t* __restrict__ counts, uint32_t* __restrict__ keys) {
     __shared__ int pos_s[27];
     order_bit_positions(counts, pos_s);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t m = row_mask[i] & 0x7FFFFFFu;
-    keys[i] = legacy ? (((uint32_t)(27 - __popc(m)) << 27) | m) : order_key_of(m, pos_s);      // legacy: round 1's key (A/B)
+    keys[i] = order_key_of(m, pos_s);
 }
 
 __global__ __launch_bounds__(256) void order_keys64_kernel(const uint32_t* __restrict__ row_mask,
@@ -301,31 +300,27 @@ __global__ __launch_bounds__(256) void order_keys64_kernel(const uint32_t* __res
     keys[i] = key;
 }
 
-__global__ __launch_bounds__(256) void iota_kernel(int32_t* __restrict__ v, int64_t n) {
+// One OR-mask per 32 execution positions (the offsets a 32-row MFMA tile has to execute).  The neighbour table itself stays
+// in output-row order: the convolution kernels read row order[pos] of it (csrc/conv.hip) — until round 4 this kernel also
+// wrote a second, permuted copy of the table (557 MB on the 5.16 M-row candidate set of a config-2 frame, read once).
+__global__ __launch_bounds__(256) void group_masks_kernel(const int32_t* __restrict__ order, const uint32_t* __restrict__ row_mask,
+                                                          int64_t n, uint32_t* __restrict__ group_mask32) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) v[i] = (int32_t)i;
+    uint32_t m = (i < n) ? row_mask[order[i]] : 0u;
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
+    if (i < n && (threadIdx.x & 31) == 0) group_mask32[i >> 5] = m;
 }
 
-// Permuted neighbour table + one OR-mask per 32 positions.  A block owns 256 consecutive positions: their source
-// rows are staged in LDS, the masks of a 32-position group are OR-reduced inside its half-wave, and the table rows
-// (K ints each, contiguous in the source) are copied with the destination fully coalesced.
-__global__ __launch_bounds__(256) void order_apply_kernel(const int32_t* __restrict__ order,
-                                                          const uint32_t* __restrict__ row_mask,
-                                                          const int32_t* __restrict__ nbr, int64_t n, int K,
-                                                          int32_t* __restrict__ nbr_sorted,
-                                                          uint32_t* __restrict__ group_mask32,
-                                                          uint32_t* __restrict__ group_mask16) {
+// out[pos] = table[order[pos]] (rows of K ints): the permuted copy of a neighbour table that the weight-gradient kernels of
+// the training path index by execution position (csrc/conv_bwd.hip).  A block owns 256 consecutive positions; the rows are
+// contiguous in the source and the destination is written fully coalesced.
+__global__ __launch_bounds__(256) void permute_rows_kernel(const int32_t* __restrict__ order, const int32_t* __restrict__ nbr,
+                                                           int64_t n, int K, int32_t* __restrict__ nbr_sorted) {
     __shared__ int32_t src_row[256];
     const int64_t r0 = (int64_t)blockIdx.x * 256;
     const int64_t i = r0 + threadIdx.x;
-    const int32_t src = (i < n) ? order[i] : 0;
-    src_row[threadIdx.x] = src;
-    uint32_t m = (i < n) ? row_mask[src] : 0u;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
-    if (group_mask16 && i < n && (threadIdx.x & 15) == 0) group_mask16[i >> 4] = m;      // 16-row MFMA tiles (pcc_conv_fwd16)
-    m |= __shfl_xor(m, 16, 64);
-    if (i < n && (threadIdx.x & 31) == 0) group_mask32[i >> 5] = m;
+    src_row[threadIdx.x] = (i < n) ? order[i] : 0;
     __syncthreads();
     const int rows = (int)((n - r0 < 256) ? (n - r0) : 256);
     const int total = rows * K;
@@ -372,8 +367,8 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void order_small_kernel(const uin
 }
 
 // ---- a small kernel map and its execution order in ONE launch -----------------------------------------------------------
-// Up to SMALL_MAP_MAX output rows: one 1024-thread workgroup runs what pcc_kernel_map + pcc_order_rows_by_mask16 run as
-// several launches (probe, row masks, offset counts, keys, the one-workgroup radix sort, permuted table + group masks).
+// Up to SMALL_MAP_MAX output rows: one 1024-thread workgroup runs what pcc_kernel_map + pcc_order_rows_by_mask run as
+// several launches (probe, row masks, offset counts, keys, the one-workgroup radix sort, group masks).
 // At these sizes every one of those launches is a few microseconds of work behind ~5 us of dispatch.  Same outputs bit for
 // bit: the same probe, the same key (rarest offset first), the same stable sort.  Measured (tools/small_map_bench.py, one
 // map, host calls included): 56 rows 22 us against 26 for kernel_map + order_small_kernel + order_apply, 300 rows 36
@@ -388,8 +383,7 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void small_map_kernel(const int32
                                                                     const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals,
                                                                     uint64_t tmask, int tshift, int step, int pitch,
                                                                     int32_t* nbr, uint32_t* __restrict__ row_mask, int32_t* order,
-                                                                    int32_t* __restrict__ nbr_sorted, uint32_t* __restrict__ group_mask32,
-                                                                    uint32_t* __restrict__ group_mask16, uint32_t* keys_a, uint32_t* keys_b,
+                                                                    uint32_t* __restrict__ group_mask32, uint32_t* keys_a, uint32_t* keys_b,
                                                                     int32_t* vals_x) {
     constexpr int ks = KS, K = KS * KS * KS;
     __shared__ unsigned rm[SMALL_MAP_MAX];
@@ -464,33 +458,13 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void small_map_kernel(const int32
     __syncthreads();
     // 27 key bits = four 8-bit passes: the sorted values (the rows, from an iota) end in the a-side = `order`
     radix_sort_small_body<uint32_t, ROUNDS>(keys_a, keys_b, order, vals_x, 1, n, 0, 27, 4);
-    // group masks (positions are consecutive across a wave's lanes) and the permuted table
+    // group masks (positions are consecutive across a wave's lanes)
     for (int i0 = 0; i0 < n; i0 += RS_SMALL_THREADS) {
         const int i = i0 + t;
         uint32_t m = (i < n) ? rm[order[i]] : 0u;
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) m |= __shfl_xor(m, d, 64);
-        if (i < n && (t & 15) == 0) group_mask16[i >> 4] = m;
-        m |= __shfl_xor(m, 16, 64);
+        for (int d = 1; d < 32; d <<= 1) m |= __shfl_xor(m, d, 64);
         if (i < n && (t & 31) == 0) group_mask32[i >> 5] = m;
-    }
-    for (int e0 = t; e0 < total; e0 += RS_SMALL_THREADS * U) {          // batched like the probes: two dependent loads per entry
-        int src[U], v[U];
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int e = e0 + j * RS_SMALL_THREADS;
-            src[j] = (e < total) ? order[e / K] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int e = e0 + j * RS_SMALL_THREADS;
-            v[j] = (e < total) ? nbr[(int64_t)src[j] * K + (e - (e / K) * K)] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < U; ++j) {
-            const int e = e0 + j * RS_SMALL_THREADS;
-            if (e < total) nbr_sorted[e] = v[j];
-        }
     }
 }
 
@@ -508,8 +482,7 @@ int64_t pcc_small_map_max(void) {
 
 int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* in_keys, const int32_t* in_vals, int64_t in_cap,
                          int32_t ksize, int32_t step, int32_t sign, int32_t* nbr, uint32_t* row_mask, int32_t* order,
-                         int32_t* nbr_sorted, uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes,
-                         void* stream) {
+                         uint32_t* group_mask32, void* scratch, int64_t scratch_bytes, void* stream) {
     PCC_REQUIRE(ksize == 2 || ksize == 3, "pcc_small_kernel_map: kernel size must be 2 or 3");
     PCC_REQUIRE(sign == 1 || sign == -1, "pcc_small_kernel_map: sign must be +1/-1");
     PCC_REQUIRE(in_cap > 0 && (in_cap & (in_cap - 1)) == 0, "pcc_small_kernel_map: bad capacity");
@@ -527,8 +500,8 @@ int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_
     hipStream_t st = as_stream(stream);
 #define PCC_SMALL_MAP(R, S)                                                                                                          \
     hipLaunchKernelGGL((small_map_kernel<R, S>), dim3(1), dim3(RS_SMALL_THREADS), 0, st, out_coords, (int)n_out, in_keys, in_vals,    \
-                       (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask, order, nbr_sorted,       \
-                       group_mask32, group_mask16, keys_a, keys_b, vals_x)
+                       (uint64_t)(in_cap - 1), grid_shift_of(in_stride), sign * step, pitch, nbr, row_mask, order,                   \
+                       group_mask32, keys_a, keys_b, vals_x)
 #define PCC_SMALL_MAP_R(S)                                                                                                           \
     do {                                                                                                                             \
         if (rounds <= 1) PCC_SMALL_MAP(1, S);                                                                                        \
@@ -572,18 +545,10 @@ int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_
 int64_t pcc_order_scratch_bytes(int64_t n) { return pcc_sort_scratch_bytes(n); }
 
 int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
-                           int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
-                           uint32_t* group_mask32, void* scratch, int64_t scratch_bytes, void* stream) {
-    return pcc_order_rows_by_mask16(row_mask, coords, n, block_log2, tensor_stride, nbr, K, order, nbr_sorted, group_mask32, nullptr,
-                                    scratch, scratch_bytes, stream);
-}
-
-int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, int64_t n, int32_t block_log2,
-                             int32_t tensor_stride, const int32_t* nbr, int32_t K, int32_t* order, int32_t* nbr_sorted,
-                             uint32_t* group_mask32, uint32_t* group_mask16, void* scratch, int64_t scratch_bytes, void* stream) {
+                           int32_t tensor_stride, int32_t* order, uint32_t* group_mask32, void* scratch, int64_t scratch_bytes,
+                           void* stream) {
     if (n <= 0) return PCC_OK;
     PCC_REQUIRE(n < (1ll << 31), "pcc_order_rows_by_mask: too many rows");
-    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_order_rows_by_mask: K out of range");
     PCC_REQUIRE(block_log2 < 0 || coords != nullptr, "pcc_order_rows_by_mask: block ordering needs coordinates");
     PCC_REQUIRE(block_log2 <= 10, "pcc_order_rows_by_mask: block_log2 out of range");
     PCC_REQUIRE(tensor_stride >= 1, "pcc_order_rows_by_mask: bad tensor stride");
@@ -595,12 +560,7 @@ int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, in
     int32_t* vals_x = reinterpret_cast<int32_t*>(p); p += align256(n * 4);
     void* counters = p;
     uint32_t* bit_counts = reinterpret_cast<uint32_t*>(p + radix_sort_counter_bytes(n));       // 27 words in the scratch's 256-byte tail
-    static int legacy = -1;      // PCC_ORDER_KEY=popcount: round 1's key (27 - popcount) << 27 | mask; =natural: rows stay in
-    if (legacy < 0) {            // the map's own (generation) order — experiments on gather locality, never the default
-        const char* e = getenv("PCC_ORDER_KEY");
-        legacy = (e && e[0] == 'p') ? 1 : (e && e[0] == 'n') ? 2 : 0;
-    }
-    if (small_path_enabled(0) && legacy == 0 && block_log2 < 0 && n <= RS_SMALL_N) {      // PCC_ORDER_SMALL=0: never (A/B)
+    if (small_path_enabled(0) && block_log2 < 0 && n <= RS_SMALL_N) {      // PCC_ORDER_SMALL=0: never (A/B)
         // counts + keys + sort in one workgroup (27 key bits = four passes: the sorted rows end in the a-side = `order`)
         const int rounds = (int)(((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
         uint32_t* ka = reinterpret_cast<uint32_t*>(keys_a);
@@ -612,21 +572,13 @@ int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, in
         else if (rounds <= 8) PCC_ORDER_SMALL(8);
         else PCC_ORDER_SMALL(16);
 #undef PCC_ORDER_SMALL
-        hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
-                           nbr_sorted, group_mask32, group_mask16);
+        hipLaunchKernelGGL(group_masks_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, n, group_mask32);
         PCC_LAUNCH_CHECK();
         return PCC_OK;
     }
     PCC_CHECK_HIP(hipMemsetAsync(bit_counts, 0, 27 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(mask_bit_counts_kernel, dim3(blocks_for(n, 256 * 16, 512)), dim3(256), 0, st, row_mask, n, bit_counts);
-    if (legacy == 2) {
-        hipLaunchKernelGGL(iota_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, n);
-        hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
-                           nbr_sorted, group_mask32, group_mask16);
-        PCC_LAUNCH_CHECK();
-        return PCC_OK;
-    }
-    const int begin = 0, end = block_log2 >= 0 ? 64 : (legacy ? 32 : 27);
+    const int begin = 0, end = block_log2 >= 0 ? 64 : 27;
     // the sorted values must land in `order`: they end in the b-side when the pass count is odd
     const bool in_b = radix_sort_result_in_b(begin, end);
     int32_t* va = in_b ? vals_x : order;
@@ -634,7 +586,7 @@ int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, in
     int rc;
     if (block_log2 < 0) {
         hipLaunchKernelGGL(order_keys32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, n, bit_counts,
-                           reinterpret_cast<uint32_t*>(keys_a), legacy);
+                           reinterpret_cast<uint32_t*>(keys_a));
         rc = radix_sort_pairs_u32(reinterpret_cast<uint32_t*>(keys_a), reinterpret_cast<uint32_t*>(keys_b), va, vb, true, n, begin, end,
                                   counters, st);
     } else {
@@ -644,8 +596,16 @@ int pcc_order_rows_by_mask16(const uint32_t* row_mask, const int32_t* coords, in
                                   counters, st);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(order_apply_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, nbr, n, K,
-                       nbr_sorted, group_mask32, group_mask16);
+    hipLaunchKernelGGL(group_masks_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, order, row_mask, n, group_mask32);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
+int pcc_permute_map_rows(const int32_t* nbr, const int32_t* order, int64_t n, int32_t K, int32_t* nbr_sorted, void* stream) {
+    PCC_REQUIRE(K >= 1 && K <= 27, "pcc_permute_map_rows: K out of range");
+    PCC_REQUIRE(nbr != nullptr && order != nullptr && nbr_sorted != nullptr, "pcc_permute_map_rows: null argument");
+    if (n <= 0) return PCC_OK;
+    hipLaunchKernelGGL(permute_rows_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, as_stream(stream), order, nbr, n, K, nbr_sorted);
     PCC_LAUNCH_CHECK();
     return PCC_OK;
 }

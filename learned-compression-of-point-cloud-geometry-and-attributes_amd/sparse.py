@@ -56,7 +56,6 @@ def _host_count():
 
 
 _SMALL_MAP_MAX = None
-_ORDER_KEY_OVERRIDE = bool(os.environ.get("PCC_ORDER_KEY")) or bool(os.environ.get("PCC_KMAP_VARIANT"))   # A/B switches of the separate launches
 
 
 def _small_map_max():
@@ -243,33 +242,30 @@ class CoordMap:
         return nbr, row_mask, pairs
 
     def ordered_kernel_map(self, out_map, ksize, transposed=False):
-        """Kernel map in MFMA execution order: (nbr_sorted [N_out, K], order [N_out], group_mask32, pair_count).
+        """Kernel map with its MFMA execution order: (nbr [N_out, K] by output row, order [N_out], group_mask32, pair_count).
 
-        Output rows are sorted by neighbour mask (optionally inside spatial blocks, ORDER_BLOCK_LOG2) so
-        that 32-row MFMA tiles skip the offsets none of their rows has."""
+        Output rows are executed sorted by neighbour mask (optionally inside spatial blocks, ORDER_BLOCK_LOG2) so that 32-row
+        MFMA tiles skip the offsets none of their rows has.  The table stays in output-row order — the kernels read row
+        order[position] of it — so ordering a map writes 4 bytes per row, not a second copy of the table."""
         key = ("okmap", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)
         hit = self._cache.get(key)
         if hit is not None and _same_map(hit[0], out_map, self):
             return hit[1:]
-        if (0 < out_map.n <= _small_map_max() and ksize in (2, 3) and ORDER_BLOCK_LOG2 < 0 and not _ORDER_KEY_OVERRIDE
+        if (0 < out_map.n <= _small_map_max() and ksize in (2, 3) and ORDER_BLOCK_LOG2 < 0
                 and ("kmap", id(out_map), ksize, transposed) not in self._cache):
             return self._small_ordered_kernel_map(out_map, ksize, transposed, key)
         nbr, row_mask, pairs = self.kernel_map(out_map, ksize, transposed)
         L = _lib.lib()
-        n_out, K = nbr.shape
+        n_out = nbr.shape[0]
         dev = self.device
         order = torch.empty(n_out, dtype=torch.int32, device=dev)
-        nbr_sorted = torch.empty_like(nbr)
         gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
-        gmask16 = torch.empty((n_out + 15) // 16, dtype=torch.int32, device=dev)      # the 16-row tiles of pcc_conv_fwd16
         nbytes = L.pcc_order_scratch_bytes(n_out)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        check(L.pcc_order_rows_by_mask16(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
-                                         ptr(nbr), K, ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch), nbytes,
-                                         _lib.stream()))
-        self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr_sorted, order, gmask, pairs)
-        self._cache[("gmask16",) + key[1:]] = gmask16
-        return nbr_sorted, order, gmask, pairs
+        check(L.pcc_order_rows_by_mask(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
+                                       ptr(order), ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
+        self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr, order, gmask, pairs)
+        return nbr, order, gmask, pairs
 
     def _small_ordered_kernel_map(self, out_map, ksize, transposed, key):
         """kernel_map + ordered_kernel_map of a small map in one launch (csrc/select.hip small_map_kernel); fills both caches"""
@@ -279,51 +275,33 @@ class CoordMap:
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=dev)
         row_mask = torch.empty(n_out, dtype=torch.int32, device=dev)
         order = torch.empty(n_out, dtype=torch.int32, device=dev)
-        nbr_sorted = torch.empty_like(nbr)
         gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
-        gmask16 = torch.empty((n_out + 15) // 16, dtype=torch.int32, device=dev)
         nbytes = L.pcc_order_scratch_bytes(n_out)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         step = self.stride // 2 if transposed else self.stride
         check(L.pcc_small_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step, -1 if transposed else 1,
-                                     ptr(nbr), ptr(row_mask), ptr(order), ptr(nbr_sorted), ptr(gmask), ptr(gmask16), ptr(scratch),
-                                     nbytes, _lib.stream()))
+                                     ptr(nbr), ptr(row_mask), ptr(order), ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
         pairs = PairCount(row_mask)
         keep = None if out_map is self else weakref.ref(out_map)
         self._cache[("kmap", id(out_map), ksize, transposed)] = (keep, nbr, row_mask, pairs)
-        self._cache[key] = (keep, nbr_sorted, order, gmask, pairs)
-        self._cache[("gmask16",) + key[1:]] = gmask16
-        return nbr_sorted, order, gmask, pairs
+        self._cache[key] = (keep, nbr, order, gmask, pairs)
+        return nbr, order, gmask, pairs
 
-    def group_mask16(self, out_map, ksize, transposed=False):
-        """per-16-position offset masks of the ordered kernel map (built with it), for the 16-row-tile convolution"""
-        self.ordered_kernel_map(out_map, ksize, transposed)
-        return self._cache[("gmask16", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)]
-
-    def compact_kernel_map(self, out_map, ksize, transposed=False):
-        """Kernel map as per-group compacted offset lists (csrc/conv_co.hip): (ent_in int32 [G, K, 256], ent_row4 int32
-        [G, K, 2, 32], cnt int16 [G, 32], pair_count) for groups of 256 consecutive output rows — the form the fp32 inference
-        convolutions run on: rows stay in the map's own order, every MFMA tile holds 32 list entries."""
-        key = ("cmap", id(out_map), ksize, transposed)
+    def position_ordered_table(self, out_map, ksize, transposed=False):
+        """the kernel map's table permuted into execution order (nbr[order]) for the weight-gradient kernels of the training
+        path, which index it by execution position (csrc/conv_bwd.hip): (nbr_sorted, order, group_mask32, pair_count)"""
+        key = ("okmap_sorted", id(out_map), ksize, transposed, ORDER_BLOCK_LOG2)
         hit = self._cache.get(key)
         if hit is not None and _same_map(hit[0], out_map, self):
             return hit[1:]
-        nbr, _, pairs = self.kernel_map(out_map, ksize, transposed)
-        L = _lib.lib()
-        n_out, K = nbr.shape
-        dev = self.device
-        groups = L.pcc_compact_map_groups(n_out)
-        ent_in = torch.empty((groups, K, COMPACT_GROUP), dtype=torch.int32, device=dev)
-        ent_row4 = torch.empty((groups, K, 2, 32), dtype=torch.int32, device=dev)
-        cnt = torch.empty((groups, 32), dtype=torch.int16, device=dev)
-        check(L.pcc_compact_map(ptr(nbr), n_out, K, ptr(ent_in), ptr(ent_row4), ptr(cnt), _lib.stream()))
-        self._cache[key] = (None if out_map is self else weakref.ref(out_map), ent_in, ent_row4, cnt, pairs)
-        return ent_in, ent_row4, cnt, pairs
+        nbr, order, gmask, pairs = self.ordered_kernel_map(out_map, ksize, transposed)
+        nbr_sorted = torch.empty_like(nbr)
+        check(_lib.lib().pcc_permute_map_rows(ptr(nbr), ptr(order), nbr.shape[0], nbr.shape[1], ptr(nbr_sorted), _lib.stream()))
+        self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr_sorted, order, gmask, pairs)
+        return nbr_sorted, order, gmask, pairs
 
     def mfma_kernel_map(self, out_map, ksize, transposed=False):
         """Build (and cache) the map form the wide inference convolutions will ask for — what the prefetchers call"""
-        if CONV_CO:
-            return self.compact_kernel_map(out_map, ksize, transposed)
         return self.ordered_kernel_map(out_map, ksize, transposed)
 
     def count_per_batch(self):
@@ -548,9 +526,6 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         return _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, out_channels)
     order = gmask = None
     bf16 = INFER_BF16 and cin % 64 == 0 and n_in * cin * 2 < 0xFFFFF000
-    if (CONV_CO and ksize > 1 and cin % 32 == 0 and cin <= 256 and cout % 64 == 0 and not bf16 and not INFER_X3
-            and n_in * cin * 4 < 0xFFFFF000 and out_map.n * ksize ** 3 * 4 < 0xFFFFE000):
-        return _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual)
     if (THIN_IM2COL and ksize > 1 and cin in (1, 2, 4, 8) and cout % 32 == 0 and ksize ** 3 * cin <= 256
             and out_map.n * ((ksize ** 3 * cin + 31) // 32 * 32) * 4 < 0xFFFFF000):
         return _thin_im2col_forward(x_feats, in_map, out_map, layer, ksize, transposed, act, film, residual, out_channels)
@@ -569,13 +544,13 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
           and (nbr is None or n_out * K * 4 < 0xFFFFF000))
     prof = PROFILER
     timed = prof is not None and n_out >= PROFILER_MIN_ROWS
-    if not timed and not bf16 and not x3 and not CONV_T16:
+    if not timed and not bf16 and not x3:
         # the default inference launch, without the bookkeeping of the other modes (a hundred of these per small frame)
-        check(L.pcc_conv_fwd16(x_feats.data_ptr(), n_in, cin, w.data_ptr(), None if wp is None else wp.data_ptr(),
-                               None if bias is None else bias.data_ptr(), None if nbr is None else nbr.data_ptr(),
-                               None if order is None else order.data_ptr(), None if gmask is None else gmask.data_ptr(), None, K,
-                               out.data_ptr(), n_out, cout, act, None if film is None else film.data_ptr(),
-                               None if residual is None else residual.data_ptr(), _lib.stream()))
+        check(L.pcc_conv_fwd(x_feats.data_ptr(), n_in, cin, w.data_ptr(), None if wp is None else wp.data_ptr(),
+                             None if bias is None else bias.data_ptr(), None if nbr is None else nbr.data_ptr(),
+                             None if order is None else order.data_ptr(), None if gmask is None else gmask.data_ptr(), K,
+                             out.data_ptr(), n_out, cout, act, None if film is None else film.data_ptr(),
+                             None if residual is None else residual.data_ptr(), _lib.stream()))
         if prof is not None:                          # counted (FLOPs, launches), not bracketed by events
             prof.append((("conv", "", nbr is not None), cin, cout, pairs if pairs is not None else n_out, n_out, None, None, gmask))
         return out
@@ -594,13 +569,8 @@ def conv_forward(x_feats, in_map, out_map, layer, ksize, transposed=False, act=A
         check(L.pcc_conv_fwd_x3(ptr(x_feats), n_in, cin, ptr(layer.weights_x3(out_channels)), ptr(bias), ptr(nbr),
                                 ptr(order), ptr(gmask), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     else:
-        g16 = in_map.group_mask16(out_map, ksize, transposed) if (CONV_T16 and gmask is not None) else None
-        check(L.pcc_conv_fwd16(ptr(x_feats), n_in, cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask),
-                               ptr(g16), K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
-        coutp = (cout + 31) // 32 * 32
-        two_tiles = coutp % 128 != 0                 # 128 x 64 and 128 x 32 workgroups: two 32-row tiles per wave (csrc/conv.hip)
-        if prof is not None and g16 is not None and (cin // 32 in (1, 2) or (cin // 32 in (4, 6) and not (two_tiles and coutp % 64 == 0))):
-            gmask = g16                              # the profiler's issued-row count follows the tile height
+        check(L.pcc_conv_fwd(ptr(x_feats), n_in, cin, ptr(w), ptr(wp), ptr(bias), ptr(nbr), ptr(order), ptr(gmask),
+                             K, ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
     if prof is not None:
         ev1.record()
     if log is not None:
@@ -617,25 +587,6 @@ def profiled_name(entry):
         _, tag, has_nbr = name
         return conv_kernel_name(cin, cout, n_out, has_nbr).replace("conv_mfma_buf_kernel", "conv_mfma_buf_kernel" + tag)
     return name
-
-
-def _conv_forward_co(x_feats, in_map, out_map, w, wp, bias, ksize, transposed, act, film, residual):
-    """the wide fp32 convolution on compacted offset lists (csrc/conv_co.hip): same result as pcc_conv_fwd, bit for bit"""
-    L = _lib.lib()
-    ent_in, ent_row4, cnt, pairs = in_map.compact_kernel_map(out_map, ksize, transposed)
-    cin, cout, n_out, K = x_feats.shape[1], w.shape[-1], out_map.n, ksize ** 3
-    out = torch.empty((n_out, cout), dtype=torch.float32, device=x_feats.device)
-    prof = PROFILER
-    if prof is not None:
-        ev0 = torch.cuda.Event(enable_timing=True)
-        ev1 = torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    check(L.pcc_conv_fwd_co(ptr(x_feats), x_feats.shape[0], cin, ptr(wp), ptr(bias), ptr(ent_in), ptr(ent_row4), ptr(cnt), K,
-                            ptr(out), n_out, cout, act, ptr(film), ptr(residual), _lib.stream()))
-    if prof is not None:
-        ev1.record()
-        prof.append((f"conv_co_kernel<{cin // 32}>", cin, cout, pairs, n_out, ev0, ev1, cnt))
-    return out
 
 
 _MFMA_VISIT = (0, 4, 1, 5, 2, 6, 3, 7)     # physical position, within 8 channels, of the t-th channel the MFMA loop contracts
@@ -696,37 +647,10 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
 THIN_IM2COL = os.environ.get("PCC_THIN_IM2COL", "1") == "1"
 
 
-# Experimental, off by default: PCC_CONV_T16=1 / set_conv_t16(True) gives the fp32 inference convolutions over kernel maps 16-row MFMA
-# tiles (v_mfma_f32_16x16x4_f32, csrc/conv.hip M16).  Bit-identical to the 32-row tiles (tests/test_conv_t16.py) and 11 % fewer
-# issued rows on the sparse sets an untrained decoder keeps (issued / useful 1.67 -> 1.48 on the 265 k-row layers), but the
-# fragment reads double in count and land 2-way on the LDS banks, which costs the same 5-10 % in issue rate: 77.4 ms of
-# convolutions per config-2 frame against 74.9 (round 3).
-CONV_T16 = os.environ.get("PCC_CONV_T16", "0") == "1"
-
-
-def set_conv_t16(enabled):
-    global CONV_T16
-    CONV_T16 = bool(enabled)
-
-
 def set_conv_small_max(workgroups):
     """Threshold (in 32 x 32 output tiles) below which a map convolution runs on the small-launch kernel (csrc/conv.hip,
     conv_small_kernel; bit-identical results); 0 = never.  Returns the previous threshold; negative = read only."""
     return int(_lib.lib().pcc_conv_small_max(int(workgroups)))
-
-
-# Experimental, off by default: PCC_CONV_CO=1 / set_conv_co(True) runs the wide fp32 inference convolutions on compacted
-# offset lists in the map's own row order (csrc/conv_co.hip) instead of the mask-ordered kernel of csrc/conv.hip.  Results
-# are bit-identical (tests/test_conv_co.py); on the config-2 frame the mask-ordered kernel is the faster one on every layer
-# class (round 3, DESIGN.md §4: 73 ms of convolutions per frame against 104 ms) — one workgroup per CU and the accumulator
-# round trip through LDS at every kernel offset cost more than full tiles and local gathers return.
-CONV_CO = os.environ.get("PCC_CONV_CO", "0") == "1"
-COMPACT_GROUP = 256        # PCC_COMPACT_GROUP of include/pcc_hip.h
-
-
-def set_conv_co(enabled):
-    global CONV_CO
-    CONV_CO = bool(enabled)
 
 
 # Output widths up to this use the narrow-head path (K * cout score columns must fit one 128-wide GEMM tile).
@@ -788,7 +712,7 @@ def conv_kernel_name(cin, cout, n_out=0, has_nbr=True):
     coutp = (cout + 31) // 32 * 32
     wgs_small = ((n_out + 31) // 32) * (coutp // 32)
     if has_nbr and CONV_BM == 0 and wgs_small <= set_conv_small_max(-1) * (1 if coutp % 128 == 0 else 2):
-        cch = cin // 32                               # (PCC_CONV_SMALL_CFG, an A/B switch, is not mirrored)
+        cch = cin // 32
         sc, ns = (4, 3) if cch % 4 == 0 and wgs_small <= 256 else (2, 3) if cch % 2 == 0 else (1, 8)
         return f"conv_small_kernel<{sc}, {ns}>"
     if coutp % 128 == 0:

@@ -64,7 +64,7 @@ def test_bf16_weight_gradient_matches_fp32_on_rounded_operands(pcc, cin, cout):
     X, G = torch.randn(n, cin), torch.randn(n, cout)
     Xb, Gb = X.to(torch.bfloat16), G.to(torch.bfloat16)
     m = pcc.CoordMap(torch.from_numpy(c).to(DEV), 1)
-    nbr, order, gmask, _ = m.ordered_kernel_map(m, 3)
+    nbr, order, gmask, _ = m.position_ordered_table(m, 3)             # the weight-gradient kernels index their table by position
     dw = torch.empty((27, cin, cout), dtype=torch.float32, device=DEV)
     ne = L.pcc_conv_wgrad_scratch_elems(27, cin, cout)
     scratch = torch.empty(ne, dtype=torch.float32, device=DEV)

@@ -189,7 +189,8 @@ def test_kernel_map(pcc, case):
     want_mask = ((nbr >= 0).astype(np.int64) << np.arange(K)).sum(axis=1)
     assert (row_mask.cpu().numpy().view(np.uint32).astype(np.int64) == want_mask).all()
     assert int(pairs.item()) == int((nbr >= 0).sum())
-    # execution order for the MFMA path: a permutation, the permuted table, OR-masks per 32 positions
+    # execution order for the MFMA path: a permutation, the table still by output row, OR-masks per 32 positions; and the
+    # permuted copy the weight-gradient kernels take
     for blk in (-1, 3):
         from pcc_amd import sparse as sp
         sp.ORDER_BLOCK_LOG2 = blk
@@ -199,7 +200,10 @@ def test_kernel_map(pcc, case):
             sp.ORDER_BLOCK_LOG2 = -1
         order = order.cpu().numpy()
         assert sorted(order.tolist()) == list(range(nbr.shape[0]))
-        assert (nbr_s.cpu().numpy() == nbr[order]).all()
+        assert (nbr_s.cpu().numpy() == nbr).all()                       # the kernels read row order[p] of the one table
+        if blk < 0:
+            nbr_p, order_p, _, _ = m.position_ordered_table(out, ks, tr)
+            assert (order_p.cpu().numpy() == order).all() and (nbr_p.cpu().numpy() == nbr[order]).all()
         gm = gm.cpu().numpy().view(np.uint32)
         sm = want_mask[order]
         for g in range(gm.shape[0]):

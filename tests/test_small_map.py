@@ -1,6 +1,6 @@
 """A small kernel map and its execution order built by ONE launch (csrc/select.hip small_map_kernel, pcc_small_kernel_map)
-against the separate launches (pcc_kernel_map + pcc_order_rows_by_mask16): every output BIT FOR BIT — neighbour table, row
-masks, order, permuted table, group masks per 32 and per 16 positions — for stride-1, strided and transposed maps, kernel
+against the separate launches (pcc_kernel_map + pcc_order_rows_by_mask): every output BIT FOR BIT — neighbour table, row
+masks, order, group masks per 32 positions — for stride-1, strided and transposed maps, kernel
 sizes 2 and 3, from one row to the 256-row limit (and past it: the one-workgroup ordering of maps up to 16,384 rows against the separate launches); and a frame coded to the same bytes either way."""
 import numpy as np
 import pytest
@@ -42,10 +42,10 @@ def _both(pcc, kind, n, seed):
         was = sp.set_small_map_max(cap)
         try:
             m, o, ks, tr = _maps(pcc, kind, n, seed)
-            nbr_sorted, order, gmask, _ = m.ordered_kernel_map(o, ks, tr)
-            g16 = m.group_mask16(o, ks, tr)
+            nbr_o, order, gmask, _ = m.ordered_kernel_map(o, ks, tr)
             nbr, row_mask, pairs = m.kernel_map(o, ks, tr)
-            outs.append([t.cpu().numpy() for t in (nbr, row_mask, order, nbr_sorted, gmask, g16)] + [int(pairs.item())])
+            assert nbr_o.data_ptr() == nbr.data_ptr()                   # one table, by output row
+            outs.append([t.cpu().numpy() for t in (nbr, row_mask, order, gmask)] + [int(pairs.item())])
         finally:
             sp.set_small_map_max(was)
     return outs
@@ -59,7 +59,7 @@ def test_one_launch_equals_separate_launches(pcc, kind, n):
     a, b = _both(pcc, kind, n, seed=n)
     if a[0].shape[0] > 256:
         pytest.skip("output set above the one-launch limit")
-    names = ("nbr", "row_mask", "order", "nbr_sorted", "group_mask32", "group_mask16")
+    names = ("nbr", "row_mask", "order", "group_mask32")
     for name, x, y in zip(names, a, b):
         assert x.shape == y.shape and np.array_equal(x, y), name
     assert a[-1] == b[-1]
@@ -81,7 +81,7 @@ c = np.concatenate([np.zeros((p.shape[0], 1)), p], axis=1).astype(np.int32)
 c = torch.from_numpy(c[np.random.default_rng(3).permutation(c.shape[0])]).to("cuda:0")
 m = pcc.CoordMap(c, 1)
 h = hashlib.sha256()
-for t in m.ordered_kernel_map(m, 3)[:3] + (m.group_mask16(m, 3),):
+for t in m.ordered_kernel_map(m, 3)[:3]:
     h.update(t.cpu().numpy().tobytes())
 print("digest", h.hexdigest())
 """ % (root, n)

@@ -49,23 +49,4 @@ for cin, cout in shapes:
             torch.cuda.synchronize()
         ms = e0.elapsed_time(e1)
         line = f"{cin:4d}->{cout:<4d} n={n} {name:7s} {ms:8.3f} ms  {2.0 * n * K * cin * cout / ms / 1e9:7.1f} TFLOP/s"
-        if cout % 64 == 0:
-            # the same table through the compacted-offset kernel (csrc/conv_co.hip): all 27 offsets present, so both kernels
-            # issue the same MFMAs — what differs is accumulators through LDS, one workgroup per CU, the list indirection
-            groups = L.pcc_compact_map_groups(n)
-            ent_in = torch.empty((groups, K, 256), dtype=torch.int32, device=dev)
-            ent_row4 = torch.empty((groups, K, 2, 32), dtype=torch.int32, device=dev)
-            cnt = torch.empty((groups, 32), dtype=torch.int16, device=dev)
-            check(L.pcc_compact_map(ptr(nbr), n, K, ptr(ent_in), ptr(ent_row4), ptr(cnt), _lib.stream()))
-            out2 = torch.empty(n, cout, device=dev)
-            for it in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                check(L.pcc_conv_fwd_co(ptr(F), n, cin, ptr(Wp), None, ptr(ent_in), ptr(ent_row4), ptr(cnt), K, ptr(out2), n, cout, 0,
-                                        None, None, _lib.stream()))
-                e1.record()
-                torch.cuda.synchronize()
-            ms2 = e0.elapsed_time(e1)
-            line += f"   | co {ms2:8.3f} ms {2.0 * n * K * cin * cout / ms2 / 1e9:7.1f} TFLOP/s  bitwise equal: {bool(torch.equal(out, out2))}"
-            del ent_in, ent_row4, cnt, out2
         print(line, flush=True)

@@ -3,7 +3,6 @@
 generative children of a 850 k-row stride-2 shell (~5 M candidates), the transposed parent->candidate kernel map,
 the candidate->candidate kernel map, and the MFMA execution order (radix sort + permuted table) of both.
 
-  PCC_KMAP_VARIANT=generic|column python tools/coord_bench.py      # A/B of the kernel-map kernels (read once per process)
 """
 import os, sys, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -35,7 +34,6 @@ def fresh():
     return pcc_amd.CoordMap(par_d, 2, nbatch=1)
 
 
-print("variant:", os.environ.get("PCC_KMAP_VARIANT", "default"))
 t, cand = timed(lambda: fresh().up(3))
 print(f"children (unique) of {par.shape[0]} parents -> {cand.n} candidates: {t:.3f} ms")
 p = fresh()

@@ -14,7 +14,7 @@ pts = syn.sphere_shell(**syn.CONFIG2)[:, :3]
 c = torch.from_numpy(np.concatenate([np.zeros((pts.shape[0], 1)), pts], 1).astype(np.int32)).to(dev)
 m1 = pcc_amd.CoordMap(c, 1, nbatch=1)
 for name, m in (("surface, stride 1", m1), ("candidates of the stride-2 surface (k3 children)", m1.down().up(3))):
-    nbr, order, gmask, pairs = m.ordered_kernel_map(m, 3)
+    nbr, order, gmask, pairs = m.position_ordered_table(m, 3)        # rows in execution order
     n = m.n
     for BM in (64, 128):
         T = n // BM

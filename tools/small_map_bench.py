@@ -18,7 +18,7 @@ for n in (56, 300, 512, 1136, 4904, 12000):
     for cap in (1 << 20, 0):
         sp.set_small_map_max(cap)
         def build():
-            for k in [k for k in m._cache if k[0] in ("kmap", "okmap", "gmask16")]:
+            for k in [k for k in m._cache if k[0] in ("kmap", "okmap")]:
                 del m._cache[k]
             m.ordered_kernel_map(m, 3)
         for _ in range(10): build()
