@@ -77,15 +77,49 @@ def free_port():
         return s_.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs this process could use, counted WITHOUT touching the HIP runtime: the visible-devices variables if set, else the
+    GPU nodes of the kernel driver's topology (/sys/class/kfd: nodes with SIMDs).  torch.cuda.device_count() would do, but on
+    ROCm it falls back to hipGetDeviceCount when amdsmi is missing, which initialises the runtime in the LAUNCHER process —
+    harmless while the ranks are child processes, wrong to rely on."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    import glob
+    n = 0
+    for path in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(path) as f:
+                for line in f:
+                    if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def launch_ranks(script, argv, n_gpus):
     """`--gpus N` with N > 1 and no RANK in the environment: start the N ranks as a child process group (torchrun, one
     rank per GPU, rendezvous on 127.0.0.1) and relay rank 0's stdout; returns the exit code for this process.  The
-    caller has not initialised the GPU (counting devices does not), and the ranks are CHILDREN, never an exec of this
-    process.  PCC_BENCH_REHEARSE=1 (every rank on cuda:0, gloo collectives — the control flow on a one-GPU box) skips the
-    device-count check; otherwise fewer visible GPUs than ranks is an error."""
+    launcher never touches the HIP runtime (visible_gpu_count reads the environment / sysfs), and the ranks are CHILDREN,
+    never an exec of this process.  PCC_BENCH_REHEARSE=1 (every rank on cuda:0, gloo collectives — the control flow on a
+    one-GPU box) skips the device-count check; otherwise fewer visible GPUs than ranks is an error (the ranks check again:
+    a rank whose device does not exist exits non-zero)."""
     import subprocess
     rehearse = os.environ.get("PCC_BENCH_REHEARSE") == "1"
-    have = torch.cuda.device_count()
+    have = visible_gpu_count()
     if not rehearse and have < n_gpus:
         print(f"{os.path.basename(script)}: --gpus {n_gpus} needs {n_gpus} visible GPUs, this host shows {have}; refusing to "
               f"run fewer ranks than asked for (PCC_BENCH_REHEARSE=1 rehearses the control flow with every rank on cuda:0 "
@@ -110,11 +144,14 @@ def launch_ranks(script, argv, n_gpus):
     return 0
 
 
-def rank_devices(dist, dev, world, rehearse):
-    """what every rank runs on, all-gathered: the `rccl` record of the result line (proof that N ranks on N devices ran)"""
+def rank_devices(dist, dev, world, rehearse, extra=None):
+    """what every rank runs on, all-gathered: the `rccl` record of the result line (proof that N ranks on N devices ran);
+    `extra`: per-rank figures to carry along (its own ms_per_step: a straggler shows in one line)"""
     p = torch.cuda.get_device_properties(dev)
     mine = {"rank": int(os.environ.get("RANK", "0")), "device": str(dev), "name": p.name,
             "pci_bus_id": getattr(p, "pci_bus_id", None), "pid": os.getpid()}
+    if extra:
+        mine.update(extra)
     if dist is None:
         return {"world": 1, "backend": None, "devices": [mine]}
     got = [None] * world
@@ -155,6 +192,9 @@ def parse():
     ap.add_argument("--no-x3-record", action="store_true", help="skip the `split_bf16` sub-record of a default run")
     ap.add_argument("--no-streamed-record", action="store_true", help="skip the `streamed` sub-record of a default run")
     ap.add_argument("--no-small-frame-record", action="store_true", help="skip the `small_frame` sub-record of a default run")
+    ap.add_argument("--no-mid-frame-record", action="store_true", help="skip the `mid_frame` sub-record of a default run")
+    ap.add_argument("--no-train-record", action="store_true", help="skip the `train_step` sub-record of a default run")
+    ap.add_argument("--no-hbm-record", action="store_true", help="skip the `roofline_hbm` record of a default run")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -205,7 +245,7 @@ def cpu_baseline(model, state_dict, sample, dev):
     parity["abs_diff"] = {"bpp": abs(parity["bpp"]["hip"] - parity["bpp"]["oracle"]),
                           "d1_psnr_db": abs(parity["d1_psnr_db"]["hip"] - parity["d1_psnr_db"]["oracle"]),
                           "y_psnr_db": abs(parity["y_psnr_db"]["hip"] - parity["y_psnr_db"]["oracle"])}
-    return {"value": n / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
+    return {"value": n / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port",
             "sample": f"one {grid}^3 sphere-shell frame, N={n} points, q=(0.5,0.5), same weights; "
                       f"t_enc={t1 - t0:.2f}s t_dec={t2 - t1:.2f}s (torch-CPU sgemm + C rANS oracle)",
             "parity": parity}
@@ -248,8 +288,6 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    rccl = rank_devices(dist, dev, world, rehearse)
-
     import pcc_amd
     from pcc_amd import sparse as sp
     syn = pcc_amd.synthetic
@@ -390,6 +428,12 @@ def main():
     device_allocs_timed = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs_before
     prof, sp.PROFILER = sp.PROFILER, None
 
+    own_ms_per_step = elapsed / args.steps * 1e3
+    rccl = rank_devices(dist, dev, world, rehearse, {"ms_per_step": round(own_ms_per_step, 3),
+                                                       "step_ms_min_max": [min(step_ms), max(step_ms)] if step_ms else None})
+    if world > 1:
+        per_rank = [d_["ms_per_step"] for d_ in rccl["devices"]]
+        rccl["ms_per_step_min_max_over_ranks"] = [min(per_rank), max(per_rank)]
     if dist is not None:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -657,6 +701,135 @@ def main():
             [jobs.put(None) for _ in workers_]
             [t.join(timeout=30) for t in workers_]
 
+    # ---- the HBM-bound (non-matrix) operators of the same frame, never `value`: coordinate sets, kernel maps, execution order,
+    # top-k, pruning, row movers — each call bracketed by HIP events on the stream it is launched on (the frame's stream or the
+    # map-prefetch side stream) in EXTRA steps after the timed ones (two events are ~9 us of host time per call: 3 ms per frame),
+    # algorithmic bytes per call from the formulas beside each call site in pcc_amd/sparse.py ----
+    roofline_hbm = None
+    if args.workload == "config2" and not blocks_mode and rank == 0 and world == 1 and not args.no_hbm_record and not args.bf16 and not args.x3:
+        try:
+            h_steps = 3
+            step(False)
+            sp.COORD_PROFILER = []
+            sp.PROFILER = []                  # the pair counts the byte formulas read are cached by the convolution log's entries
+            for _ in range(h_steps):
+                step(False)
+            torch.cuda.synchronize()
+            clog, sp.COORD_PROFILER, sp.PROFILER = sp.COORD_PROFILER, None, None
+            ops = {}
+            for name, rows, alg, e0, e1, on_main in clog:
+                o = ops.setdefault(name, dict(calls=0, ms=0.0, ms_main=0.0, bytes=0.0, rows=0, max_ms=0.0, max_rows=0))
+                ms = e0.elapsed_time(e1)
+                o["calls"] += 1
+                o["ms"] += ms
+                o["ms_main"] += ms if on_main else 0.0
+                o["bytes"] += float(alg() if callable(alg) else alg)
+                o["rows"] += rows
+                if ms > o["max_ms"]:
+                    o["max_ms"], o["max_rows"] = ms, rows
+            tj = latest_profile("hbm_kernel_traffic")
+            classes_h = []
+            for name, o in sorted(ops.items(), key=lambda kv: -kv[1]["ms"]):
+                gbps = o["bytes"] / (o["ms"] * 1e-3) / 1e9 if o["ms"] > 0 else 0.0
+                rec = {"operator": name, "calls_per_step": o["calls"] / h_steps, "ms_per_step": o["ms"] / h_steps,
+                       "ms_per_step_on_main_stream": o["ms_main"] / h_steps,
+                       "algorithmic_mb_per_step": o["bytes"] / h_steps / 1e6, "achieved": gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": gbps / HBM_PEAK_GBS, "largest_call": {"rows": o["max_rows"], "ms": o["max_ms"]}}
+                if tj is not None and name in tj.get("operators", {}):
+                    t_ = tj["operators"][name]
+                    rec["traffic"] = t_.get("hbm_bytes_per_step")
+                    rec["traffic_kernels"] = t_.get("kernels")
+                classes_h.append(rec)
+            tot = sum(o["ms"] for o in ops.values()) / h_steps
+            tot_main = sum(o["ms_main"] for o in ops.values()) / h_steps
+            roofline_hbm = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "steps": h_steps,
+                            "ms_per_step": tot, "ms_per_step_on_main_stream": tot_main,
+                            "ms_per_step_on_prefetch_stream": tot - tot_main,
+                            "algorithmic_mb_per_step": sum(o["bytes"] for o in ops.values()) / h_steps / 1e6,
+                            "achieved": sum(o["bytes"] for o in ops.values()) / max(sum(o["ms"] for o in ops.values()), 1e-9) / 1e6,
+                            "operators": classes_h,
+                            "traffic_source": None if tj is None else {
+                                "file": tj["_file"], "taken_at_commit": tj.get("commit"),
+                                "kernel_source_unchanged_since": tj.get("kernel_source_sha256") == kernel_source_sha256(),
+                                "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, per kernel name, FETCH x2 "
+                                       "gfx950 correction (tools/pmc_traffic.py --all); replayed from the committed file"},
+                            "note": "per OPERATOR call (a call is one to ten kernels: an execution order = offset counts, keys, four radix "
+                                    "passes, group masks), HIP events on the launching stream in 3 extra steps after the timed ones; "
+                                    "times of calls on the prefetch stream overlap the convolutions of the main stream"}
+            roofline_hbm["frac"] = roofline_hbm["achieved"] / HBM_PEAK_GBS
+        except Exception as e:                                   # a sub-record must not take the headline down with it
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            sp.COORD_PROFILER = None
+            roofline_hbm = {"error": repr(e)[:300]}
+
+    # ---- a mid-size frame (125,672 points: one rank's share of the config-2 frame in whole-frame-over-8-GPUs mode), never
+    # `value`: the frame every rank of the spatial-block mode sees ----
+    mid_frame_record = None
+    if (args.workload == "config2" and not blocks_mode and not args.bf16 and not args.x3 and not args.no_mid_frame_record
+            and rank == 0 and world == 1 and not args.file_mode):
+        try:
+            m_pts = syn.sphere_shell(grid=256, radius=100.0, half_width=0.5)
+            m_qc, m_qf = syn.uniform_qmap(m_pts[:, :3], 0.5, 0.5)
+            mx, mqc, mqf = torch.from_numpy(m_pts).to(dev), torch.from_numpy(m_qc).to(dev), torch.from_numpy(m_qf).to(dev)
+
+            def mid_steps(n_steps):
+                te = td = 0.0
+                for _ in range(n_steps):
+                    torch.cuda.synchronize()
+                    a0 = time.perf_counter()
+                    Qm = pcc_amd.SparseTensor(coordinates=mqc, features=mqf, device=dev)
+                    ms_, mshape, mk, mc = model.compress(mx, Qm)
+                    torch.cuda.synchronize()
+                    a1 = time.perf_counter()
+                    model.decompress(coordinates=mc, strings=ms_, shape=mshape, k=mk)
+                    torch.cuda.synchronize()
+                    a2 = time.perf_counter()
+                    te += a1 - a0
+                    td += a2 - a1
+                return te / n_steps * 1e3, td / n_steps * 1e3
+
+            mid_steps(4)
+            reps = sorted((mid_steps(10) for _ in range(3)), key=lambda r: r[0] + r[1])
+            m_e, m_d = reps[1]
+            pro_rata = elapsed / args.steps * 1e3 * m_pts.shape[0] / N
+            mid_frame_record = {"workload": "256^3 sphere shell, N=%d points" % m_pts.shape[0], "ms_per_frame": m_e + m_d,
+                                "ms_per_frame_min_max": [reps[0][0] + reps[0][1], reps[2][0] + reps[2][1]],
+                                "t_enc_ms": m_e, "t_dec_ms": m_d, "value": m_pts.shape[0] / (m_e + m_d) / 1e3, "unit": "Mpoints/s",
+                                "pro_rata_of_the_full_frame_ms": pro_rata, "over_pro_rata": (m_e + m_d) / pro_rata,
+                                "note": "median of three repetitions of 10 frames; the share of the config-2 frame one of eight ranks "
+                                        "codes in the spatial-block mode: its time over the pro-rata time is what strong scaling can "
+                                        "reach at best before any communication"}
+        except Exception as e:
+            mid_frame_record = {"error": repr(e)[:300]}
+
+    # ---- the training step (BASELINE config 5's shape on one GPU), never `value`: tools/train_bench.py as a
+    # CHILD process (its own model in training mode, Adam, 8 cubes of 256^3 = ~812 k points per step), fp32 and bf16 operands ----
+    train_record = None
+    if (args.workload == "config2" and not blocks_mode and not args.bf16 and not args.x3 and not args.no_train_record
+            and rank == 0 and world == 1 and not args.file_mode):
+        import subprocess
+        train_record = {}
+        torch.cuda.empty_cache()
+        for tag, env_add in (("f32", {}), ("bf16_operands", {"PCC_TRAIN_BF16": "1"})):
+            try:
+                env = dict(os.environ, **env_add)
+                for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PCC_BENCH_FORCE_DIST", "PCC_BENCH_REHEARSE"):
+                    env.pop(k_, None)
+                r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--batch", "8", "--block", "256",
+                                     "--steps", "5", "--warmup", "3"], env=env, capture_output=True, text=True, timeout=420)
+                line = next((ln for ln in reversed(r_.stdout.splitlines()) if ln.lstrip().startswith("{")), None)
+                if r_.returncode != 0 or line is None:
+                    train_record[tag] = {"error": (r_.stderr or r_.stdout)[-300:]}
+                    continue
+                j_ = json.loads(line)
+                train_record[tag] = {"ms_per_step": j_["ms_per_step"], "value": j_["value"] / 1e6, "unit": "Mpoints/s",
+                                     "points_per_step": j_["points_per_step"], "last_loss": j_["last_loss"], "dtype": j_["dtype"]}
+            except Exception as e:
+                train_record[tag] = {"error": repr(e)[:300]}
+        train_record["note"] = ("tools/train_bench.py --batch 8 --block 256 --steps 5 --warmup 3 in a child process: forward + loss + "
+                                "backward + Adam of configs/Ours.yaml on 8 cubes cut from the config-2 frame, one MI355X")
+
     # ---- per-kernel-class accounting from the HIP events recorded around every conv launch ----
     classes = {}
     pop_cache = {}
@@ -680,16 +853,25 @@ def main():
         name, cin, cout, pairs, n_out, e0, e1, gmask = entry
         name = sp.profiled_name(entry)
         p = int(pairs.item()) if torch.is_tensor(pairs) else int(pairs)
-        c = classes.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, gather_bytes=0.0, exec_flops=0.0))
+        c = classes.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, gather_bytes=0.0, exec_flops=0.0, untimed_launches=0,
+                                          untimed_flops=0.0))
         ex = 0.0 if name.startswith("narrow") else 2.0 * 32 * active_slots(gmask, n_out) * cin * ((cout + 31) // 32 * 32)
-        ms = e0.elapsed_time(e1) if e0 is not None else 0.0      # launches below sp.PROFILER_MIN_ROWS rows carry no events
+        if e0 is None:
+            # launches below sp.PROFILER_MIN_ROWS rows carry no events: their FLOPs count towards the step's total only, so that a
+            # class's rate, average launch time and bytes per launch all describe the same (timed) launches
+            c["untimed_launches"] += 1
+            c["untimed_flops"] += 2.0 * p * cin * cout
+            launches.append((0.0, name, cin, cout, n_out, p, ex))
+            continue
+        ms = e0.elapsed_time(e1)
         launches.append((ms, name, cin, cout, n_out, p, ex))
         c["exec_flops"] += ex
         c["launches"] += 1
         c["ms"] += ms
         c["flops"] += 2.0 * p * cin * cout
         c["gather_bytes"] += 4.0 * (p * cin + n_out * cout)
-    dom_name = max(classes, key=lambda n: classes[n]["ms"]) if classes else None
+    timed_classes = {n_: c for n_, c in classes.items() if c["launches"]}
+    dom_name = max(timed_classes, key=lambda n: timed_classes[n]["ms"]) if timed_classes else None
     roofline = None
     if dom_name:
         d = classes[dom_name]
@@ -757,6 +939,8 @@ def main():
                   file=sys.stderr)
         per_step = len(launches) // args.steps
         for ms, n_, cin, cout, n_out, p, ex in sorted(launches[:per_step], key=lambda t: -t[0])[:int(os.environ.get("PCC_BENCH_TOP", "16"))]:
+            if ms <= 0.0:
+                continue
             print(f"    {n_[:34]:34s} {cin:4d}->{cout:<4d} rows {n_out:8d} nbrs/row {p / max(n_out, 1):5.1f}  {ms:7.3f} ms  "
                   f"alg {2.0 * p * cin * cout / ms / 1e9:6.1f} TF/s  issued {ex / ms / 1e9:6.1f} TF/s", file=sys.stderr)
         print(f"  conv total {tot_ms / args.steps:.2f} ms/step of {elapsed / args.steps * 1e3:.2f} ms/step; "
@@ -822,7 +1006,7 @@ def main():
               "otherwise walks ~215 k interpreter objects (80-135 ms) and the per-launch records of this script provoke one per 20 "
               "steps; no device memory depends on the collector (device_allocs_during_timed_steps)",
         "bpp": bpp,
-        "conv_gflop_per_step": sum(c["flops"] for c in classes.values()) / args.steps / 1e9,
+        "conv_gflop_per_step": sum(c["flops"] + c["untimed_flops"] for c in classes.values()) / args.steps / 1e9,
         "roofline": roofline,
         "rccl": rccl,
     }
@@ -832,15 +1016,29 @@ def main():
         out["split_bf16"] = x3_record
     if streamed_record is not None:
         out["streamed"] = streamed_record
+    if roofline_hbm is not None:
+        out["roofline_hbm"] = roofline_hbm
     if small_frame_record is not None:
         out["small_frame"] = small_frame_record
+    if mid_frame_record is not None:
+        out["mid_frame"] = mid_frame_record
+    if train_record is not None:
+        out["train_step"] = train_record
     if file_mode is not None:
         out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {n_: t.detach().cpu() for n_, t in model.state_dict().items()}
         out["cpu_baseline"] = cpu_baseline(model, sd, args.cpu_sample, dev)
     elif rank == 0:
-        out["cpu_baseline"] = None
+        # N > 1 (and --no-cpu-baseline): the baseline is measured on rank 0 at N = 1 only (minutes of host work); carry the newest
+        # committed N = 1 record along, labelled as replayed, so that a scaling line is as complete as the N = 1 line
+        prev = latest_profile("bench_config2")
+        cb = (prev or {}).get("cpu_baseline")
+        if cb:
+            cb = dict(cb)
+            cb["replayed_from"] = {"file": prev["_file"], "commit": prev.get("commit"),
+                                   "note": "measured by the N = 1 run of this command on one MI355X box's host cores; not re-measured in this run"}
+        out["cpu_baseline"] = cb
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:

@@ -228,25 +228,26 @@ __global__ __launch_bounds__(256) void coords_to_keys(const int32_t* __restrict_
 // key (27 - popcount) << 27 | mask; candidate sets (437 distinct masks) are at 1.00 either way.  Descending = rows holding
 // the rare (corner) offsets, the heavy ones, first: tiles are dispatched in key order, so a launch ends on its cheap tiles.
 // With spatial blocks the block id goes on top (64-bit key).
+// rows per offset.  One ballot per offset and 64 rows (the count of an offset over a wave's rows is the popcount of the
+// ballot: a scalar add) instead of one shift-and-add per offset and ROW — 27 x 64 vector operations per 64 rows before.
 __global__ __launch_bounds__(256) void mask_bit_counts_kernel(const uint32_t* __restrict__ row_mask, int64_t n,
                                                               uint32_t* __restrict__ counts) {
     __shared__ unsigned c[27];
     if (threadIdx.x < 27) c[threadIdx.x] = 0u;
     __syncthreads();
-    unsigned mine[27];
+    unsigned mine[27];                                   // wave-uniform
 #pragma unroll
     for (int b = 0; b < 27; ++b) mine[b] = 0u;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const uint32_t m = row_mask[i];
+    for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += (int64_t)gridDim.x * 256) {
+        const int64_t i = i0 + threadIdx.x;
+        const uint32_t m = (i < n) ? row_mask[i] : 0u;
 #pragma unroll
-        for (int b = 0; b < 27; ++b) mine[b] += (m >> b) & 1u;
+        for (int b = 0; b < 27; ++b) mine[b] += (unsigned)__popcll(__ballot((m >> b) & 1u));
     }
+    if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-    for (int b = 0; b < 27; ++b) {
-        unsigned v = mine[b];
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&c[b], v);
+        for (int b = 0; b < 27; ++b)
+            if (mine[b]) atomicAdd(&c[b], mine[b]);
     }
     __syncthreads();
     if (threadIdx.x < 27 && c[threadIdx.x]) atomicAdd(&counts[threadIdx.x], c[threadIdx.x]);

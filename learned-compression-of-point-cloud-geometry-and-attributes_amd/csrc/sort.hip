@@ -18,7 +18,7 @@
 //                     global-load latency once instead of once per round;
 //   n <= 512 K        per pass two launches: per-workgroup digit histograms (2048 keys per workgroup), then the
 //                     scatter kernel, which sums the histograms of the workgroups in front of it itself (<= 256 of them);
-//   larger            per pass three launches: histograms (8192 keys per workgroup), one scan workgroup per digit
+//   larger            per pass three launches: histograms (4096 keys per workgroup), one scan workgroup per digit
 //                     over that digit's row of counters, scatter.
 #include "sort_small.h"
 
@@ -26,7 +26,7 @@ namespace pcc {
 
 constexpr int RS_MID_ITEMS = 8;                   // keys per lane: 2048-key workgroups, self-prefixed scatter
 constexpr int RS_MID_MAX_UNITS = 256;             // n <= 524,288
-constexpr int RS_BIG_ITEMS = 32;                  // 8192-key workgroups, row-scan kernel between count and scatter
+constexpr int RS_BIG_ITEMS = 16;                  // 4096-key workgroups (48 KB of LDS for 64-bit keys: three per CU), row-scan kernel between count and scatter
 
 template <class K, int ROUNDS>
 __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* ka, K* kb, int32_t* va, int32_t* vb, int iota, int n,
@@ -92,18 +92,31 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t* __restrict_
 
 // SELF_PREFIX: `counts` holds the raw histograms; thread d sums its digit's row in front of this workgroup and over all
 // workgroups itself (nunits <= RS_MID_MAX_UNITS).  Otherwise `counts` is row-scanned and `totals` holds the row sums.
+//
+// The workgroup's pairs are first sorted LOCALLY into LDS (digit-major, input order inside a digit: the same stable ranks
+// as before, relative to the workgroup instead of to the whole array) and then written out position by position, so that
+// consecutive lanes write consecutive global positions: a digit's run of this workgroup (32 pairs on average at 8192 keys)
+// leaves as whole 128-byte lines.  Until round 4 every lane wrote its pair straight to its global position — 64 lanes, up
+// to 64 different lines per instruction, each (wave, digit) cursor advancing 4 bytes at a time over 32 rounds: with 4096
+// waves x 256 cursors x 2 arrays in flight the partially written lines (256 MB) fell out of the 32 MB of L2 long before
+// they were full, and a 5.16 M-pair pass took 0.42 ms for 82 MB (0.2 TB/s).
 template <class K, int ITEMS, bool SELF_PREFIX>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict__ src, K* __restrict__ dst, const int32_t* __restrict__ vs,
                                                             int32_t* __restrict__ vd, int iota, int64_t n, int shift, unsigned dmask,
                                                             int64_t nunits, const int32_t* __restrict__ counts,
                                                             const int32_t* __restrict__ totals) {
-    __shared__ int cnt[4][256];
-    __shared__ int wsum[4];
-    constexpr int WAVE_KEYS = 64 * ITEMS;
+    constexpr int WAVE_KEYS = 64 * ITEMS, WG_KEYS = 4 * WAVE_KEYS;
+    __shared__ K skey[WG_KEYS];
+    __shared__ int32_t sval[WG_KEYS];
+    __shared__ int cnt[4][256];          // per wave: digit counts, then the wave's cursor into the local order
+    __shared__ int lbase[256];           // first local position of a digit
+    __shared__ int gbase[256];           // global position of the digit's first pair of this workgroup
+    __shared__ int wsum[4], wsum2[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
     for (int i = t; i < 4 * 256; i += 256) (&cnt[0][0])[i] = 0;
-    const int64_t wbase = (int64_t)blockIdx.x * (4 * WAVE_KEYS) + (int64_t)w * WAVE_KEYS;
+    const int64_t base0 = (int64_t)blockIdx.x * WG_KEYS;
+    const int64_t wbase = base0 + (int64_t)w * WAVE_KEYS;
     K key[ITEMS];
     int32_t val[ITEMS];
 #pragma unroll
@@ -134,15 +147,23 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
     const int inc = wave_inclusive_scan_i32(total, lane);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    {   // global base of digit t for this workgroup, then for each of its waves (input order)
+    {   // digit t: its global base for this workgroup; its local base (exclusive scan of the workgroup's digit counts);
+        // then each wave's cursor into the local order (waves in input order)
         int run = pre + inc - total;
         for (int ww = 0; ww < w; ++ww) run += wsum[ww];
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-            const int c = cnt[ww][t];
-            cnt[ww][t] = run;
-            run += c;
-        }
+        const int c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+        const int mine = c0 + c1 + c2 + c3;
+        const int linc = wave_inclusive_scan_i32(mine, lane);
+        if (lane == 63) wsum2[w] = linc;
+        __syncthreads();
+        int lrun = linc - mine;
+        for (int ww = 0; ww < w; ++ww) lrun += wsum2[ww];
+        gbase[t] = run;
+        lbase[t] = lrun;
+        cnt[0][t] = lrun;
+        cnt[1][t] = lrun + c0;
+        cnt[2][t] = lrun + c0 + c1;
+        cnt[3][t] = lrun + c0 + c1 + c2;
     }
     __syncthreads();
 #pragma unroll
@@ -154,13 +175,21 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
         int base = 0;
         if (active) {
             base = cnt[w][d];
-            const int64_t pos = (int64_t)base + below;
-            dst[pos] = key[j];
-            vd[pos] = val[j];
+            skey[base + below] = key[j];
+            sval[base + below] = val[j];
         }
         __builtin_amdgcn_wave_barrier();
         if (active && below == 0) cnt[w][d] = base + __popcll(same);
         __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    const int nk = (int)((n - base0 < WG_KEYS) ? (n - base0) : WG_KEYS);
+    for (int i = t; i < nk; i += 256) {
+        const K k = skey[i];
+        const unsigned d = (unsigned)(k >> shift) & dmask;
+        const int64_t pos = (int64_t)gbase[d] + (i - lbase[d]);
+        dst[pos] = k;
+        vd[pos] = sval[i];
     }
 }
 

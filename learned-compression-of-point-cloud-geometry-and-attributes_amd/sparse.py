@@ -30,6 +30,30 @@ def _require_cuda(t):
                            "there is no CPU fallback")
 
 
+# Optional log of the HBM-bound (non-matrix) operators for bench.py's `roofline_hbm` record: a list that receives
+# (operator class, rows, algorithmic bytes or a callable returning them, start event, end event, on the main stream?) per call.
+# Events are recorded on the stream the kernels are launched on (torch's current stream: the frame's own or the map-prefetch
+# side stream).  Off (None) in the timed steps of a benchmark: two events are ~9 us of host time per call.
+COORD_PROFILER = None
+
+
+def _cp_begin():
+    if COORD_PROFILER is None:
+        return None
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
+def _cp_end(ev0, name, rows, alg_bytes):
+    if ev0 is None or COORD_PROFILER is None:
+        return
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev1.record()
+    main = torch.cuda.current_stream() == torch.cuda.default_stream()       # else: the map-prefetch side stream
+    COORD_PROFILER.append((name, int(rows), alg_bytes, ev0, ev1, main))
+
+
 def _as_int_coords(coords):
     """ME floors non-int32 coordinates (reference: model/model.py:184-188, utils.py:438)."""
     if coords.dtype.is_floating_point:
@@ -180,7 +204,9 @@ class CoordMap:
             cap = L.pcc_hash_capacity(self.n)
             keys = torch.empty(cap, dtype=torch.int64, device=self.device)
             vals = torch.empty(cap, dtype=torch.int32, device=self.device)
+            ev = _cp_begin()
             check(L.pcc_hash_build(ptr(self.coords), self.n, ptr(keys), ptr(vals), cap, self.stride, None, _lib.stream()))
+            _cp_end(ev, "hash_build", self.n, 28 * self.n + 12 * cap)      # table cleared (12 B / slot), coordinates read, key + value written
             self._table = (keys, vals, cap)
         return self._table
 
@@ -189,7 +215,9 @@ class CoordMap:
         keys, vals, cap = self.table()
         q = _as_int_coords(query)
         out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
+        ev = _cp_begin()
         check(_lib.lib().pcc_hash_lookup(ptr(keys), ptr(vals), cap, self.stride, ptr(q), q.shape[0], ptr(out), _lib.stream()))
+        _cp_end(ev, "hash_lookup", q.shape[0], 32 * q.shape[0])           # coordinate, key probe, value, index written
         return out
 
     # -- derived coordinate sets -------------------------------------------------------------
@@ -202,9 +230,12 @@ class CoordMap:
         scratch = torch.empty(L.pcc_scan_scratch_elems(m), dtype=torch.int32, device=dev)
         out = torch.empty((max(m, 1), 4), dtype=torch.int32, device=dev)
         count = _host_count()
+        ev = _cp_begin()
         check(getattr(L, fn_name)(ptr(self.coords), self.n, *args, ptr(keys), ptr(vals), cap, ptr(scratch),
                                   ptr(out), ptr(count), _lib.stream()))
         n_out = _read_count(count, dev)      # the one host sync of a coordinate-set construction
+        # table cleared, 16 B per source row, 12 B per candidate (key claim + flag), 16 B + 12 B per unique row written
+        _cp_end(ev, "unique_" + fn_name[4:], m, 12 * cap + 16 * self.n + 12 * m + 28 * n_out)
         return out[:n_out], (keys, vals, cap)
 
     def down(self):
@@ -234,9 +265,14 @@ class CoordMap:
         nbr = torch.empty((n_out, K), dtype=torch.int32, device=self.device)
         row_mask = torch.empty(n_out, dtype=torch.int32, device=self.device)
         step = self.stride // 2 if transposed else self.stride
+        ev = _cp_begin()
         check(_lib.lib().pcc_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step,
                                         -1 if transposed else 1, ptr(nbr), ptr(row_mask), None, _lib.stream()))
         pairs = PairCount(row_mask)
+        # per row: coordinates 16 B, K key probes of 8 B (a transposed map probes only on-grid parents: ~K / 8), a value per
+        # hit, K indices and the mask written
+        probes = K * n_out if not transposed else max(n_out, K * n_out // 8)
+        _cp_end(ev, "kernel_map", n_out, lambda: 20 * n_out + 8 * probes + 4 * int(pairs) + 4 * K * n_out)
         # the entry remembers out_map weakly (_same_map): id() alone could be reused, a strong reference makes cycles
         self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr, row_mask, pairs)
         return nbr, row_mask, pairs
@@ -262,8 +298,11 @@ class CoordMap:
         gmask = torch.empty((n_out + 31) // 32, dtype=torch.int32, device=dev)
         nbytes = L.pcc_order_scratch_bytes(n_out)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        ev = _cp_begin()
         check(L.pcc_order_rows_by_mask(ptr(row_mask), ptr(out_map.coords), n_out, ORDER_BLOCK_LOG2, out_map.stride,
                                        ptr(order), ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
+        # offset counts 4 B, keys 4 + 4 B, four radix passes of (4 B counted + 8 B read + 8 B written), group masks 8 B per row
+        _cp_end(ev, "execution_order", n_out, 100 * n_out)
         self._cache[key] = (None if out_map is self else weakref.ref(out_map), nbr, order, gmask, pairs)
         return nbr, order, gmask, pairs
 
@@ -279,9 +318,11 @@ class CoordMap:
         nbytes = L.pcc_order_scratch_bytes(n_out)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         step = self.stride // 2 if transposed else self.stride
+        ev = _cp_begin()
         check(L.pcc_small_kernel_map(ptr(out_map.coords), n_out, ptr(keys), ptr(vals), cap, ksize, step, -1 if transposed else 1,
                                      ptr(nbr), ptr(row_mask), ptr(order), ptr(gmask), ptr(scratch), nbytes, _lib.stream()))
         pairs = PairCount(row_mask)
+        _cp_end(ev, "small_map+order", n_out, (120 + 12 * K) * n_out)
         keep = None if out_map is self else weakref.ref(out_map)
         self._cache[("kmap", id(out_map), ksize, transposed)] = (keep, nbr, row_mask, pairs)
         self._cache[key] = (keep, nbr, order, gmask, pairs)
@@ -319,7 +360,9 @@ class CoordMap:
         nbytes = L.pcc_sort_scratch_bytes(self.n)
         scratch = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
         perm = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        ev = _cp_begin()
         check(L.pcc_sort_coords(ptr(self.coords), self.n, ptr(perm), ptr(scratch), nbytes, _lib.stream()))
+        _cp_end(ev, "canonical_sort", self.n, (24 + 8 * 32) * self.n)        # keys made, eight passes of (8 counted + 12 read + 12 written)
         return perm
 
 
@@ -421,7 +464,9 @@ def gather_rows(src, idx, out=None, accumulate=False):
     c = src.shape[1]
     if out is None:
         out = torch.empty((n, c), dtype=torch.float32, device=src.device)
+    ev = _cp_begin()
     check(_lib.lib().pcc_gather_rows(ptr(src), c, ptr(idx), n, ptr(out), 1 if accumulate else 0, _lib.stream()))
+    _cp_end(ev, "gather_rows", n, (4 + (12 if accumulate else 8) * c) * n)
     return out
 
 
@@ -489,9 +534,12 @@ def compact_rows(mask, coords=None, feats=None, want_index=False):
     c = feats.shape[1] if feats is not None else 0
     out_f = torch.empty((n, c), dtype=torch.float32, device=dev) if feats is not None else None
     new_index = torch.empty(n, dtype=torch.int32, device=dev) if want_index else None
+    ev = _cp_begin()
     check(L.pcc_compact_rows(ptr(mask), n, ptr(coords), ptr(out_c), ptr(feats), c, ptr(out_f), ptr(new_index),
                              ptr(scratch), ptr(count), _lib.stream()))
     m = _read_count(count, dev)
+    # mask + scan per row, coordinates and features of the kept rows read and written
+    _cp_end(ev, "prune", n, 13 * n + (2 * (16 if coords is not None else 0) + 8 * c) * m)
     return (out_c[:m] if out_c is not None else None, out_f[:m] if out_f is not None else None, new_index, m)
 
 
@@ -510,8 +558,10 @@ def topk_mask(logits, coords, k_per_batch, nbatch):
         k = torch.tensor(ks, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
     state = torch.empty(L.pcc_topk_state_elems(nbatch), dtype=torch.int32, device=dev)
     mask = torch.empty(n, dtype=torch.uint8, device=dev)
+    ev = _cp_begin()
     check(L.pcc_topk_mask(ptr(logits), logits.stride(0), ptr(coords), n, nbatch, ptr(k), ptr(mask), ptr(state),
                           _lib.stream()))
+    _cp_end(ev, "top_k", n, 37 * n)               # four passes over the fp32 logit, then logit + coordinates read, mask written
     return mask
 
 
@@ -608,7 +658,9 @@ def _thin_im2col_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         ev0.record()
+    ev = _cp_begin()
     check(L.pcc_im2col_thin(ptr(x_feats), cin, ptr(nbr), n_out, K, ptr(x2), k2, _lib.stream()))
+    _cp_end(ev, "im2col_thin", n_out, lambda: 4 * K * n_out + 4 * cin * int(pairs) + 4 * k2 * n_out)
     check(L.pcc_conv_fwd(ptr(x2), n_out, k2, None, ptr(w2p), ptr(bias), None, None, None, 1, ptr(out), n_out, cout, act, ptr(film),
                          ptr(residual), _lib.stream()))
     if prof is not None:
@@ -635,7 +687,9 @@ def _narrow_head_forward(x_feats, in_map, out_map, layer, ksize, transposed, act
         ev0.record()
     check(L.pcc_conv_fwd(ptr(x_feats), n_in, cin, ptr(w_r), ptr(wp_r), None, None, None, None, 1, ptr(scores), n_in, ld,
                          ACT_NONE, None, None, _lib.stream()))
+    ev = _cp_begin()
     check(L.pcc_gather_sum_fwd(ptr(scores), ld, ptr(nbr), K, cout, ptr(bias), ptr(out), n_out, act, _lib.stream()))
+    _cp_end(ev, "gather_sum", n_out, lambda: 4 * K * n_out + 4 * cout * int(pairs) + 4 * cout * n_out)
     if prof is not None:
         ev1.record()
         prof.append((f"narrow_head<{cin}>", cin, cout, pairs, n_out, ev0, ev1, None))

@@ -183,7 +183,7 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0",
             assert_contract(bpp, o_bpp, m, om, tag)
         else:
             # different encodings of the frame (module docstring): the kernel-order equality below is then mandatory
-            assert exact, (tag, "n_sym > 0 needs the kernel-order comparison")
+            assert exact, (tag, "n_sym > 0 needs the kernel-order comparison (exact=True, or \"elsewhere\" naming the test that makes it)")
             assert abs(bpp - o_bpp) <= CONTRACT_BPP, (tag, "bpp", bpp, o_bpp)
             for key in ("sym_psnr_mse", "sym_y_psnr"):
                 if np.isfinite(m[key]) or np.isfinite(om[key]):
@@ -204,7 +204,7 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0",
             for key in ("sym_psnr_mse", "sym_y_psnr"):
                 if np.isfinite(m[key]) or np.isfinite(om[key]):
                     assert abs(m[key] - om[key]) <= CONTRACT_DB + SYMBOL_FLIP_DB * n_sym, (tag, key, m[key], om[key], n_sym)
-    if exact:
+    if exact is True:                      # "elsewhere": the same frame's equality test lives in another test (named by the caller)
         assert_exact(oracle_codec, pts, qc, qf, strings, shape, k, got_c, rec, tag)
     return dict(bpp=bpp, o_bpp=o_bpp, m=m, om=om, flips=flips, flips_same=flips_same, n_sym=n_sym,
                 streams_equal=(strings == o_strings), d_d1=abs(m["sym_psnr_mse"] - om["sym_psnr_mse"]),

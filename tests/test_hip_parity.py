@@ -478,8 +478,8 @@ def test_mask_order_is_the_stable_sort_of_the_keys(pcc, n, K):
     gm = torch.empty((n + 31) // 32, dtype=torch.int32, device=DEV)
     nbytes = L.pcc_order_scratch_bytes(n)
     scratch = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    check(L.pcc_order_rows_by_mask(ptr(d_mask), None, n, -1, 1, ptr(d_nbr), K, ptr(order), ptr(nbr_s), ptr(gm), ptr(scratch), nbytes,
-                                   stream()))
+    check(L.pcc_order_rows_by_mask(ptr(d_mask), None, n, -1, 1, ptr(order), ptr(gm), ptr(scratch), nbytes, stream()))
+    check(L.pcc_permute_map_rows(ptr(d_nbr), ptr(order), n, K, ptr(nbr_s), stream()))      # the training path's permuted copy
     key = order_key(mask)
     want = np.argsort(key, kind="stable")
     got = order.cpu().numpy()
