@@ -25,7 +25,7 @@
 namespace pcc {
 
 constexpr int RS_MID_ITEMS = 8;                   // keys per lane: 2048-key workgroups, self-prefixed scatter
-constexpr int RS_MID_MAX_UNITS = 256;             // n <= 524,288
+constexpr int RS_MID_MAX_UNITS = 64;              // n <= 131,072 (a thread sums its digit's row of unit counters itself: 265 k rows took 150 us this way, 850 k rows 132 us the other)
 constexpr int RS_BIG_ITEMS = 16;                  // 4096-key workgroups (48 KB of LDS for 64-bit keys: three per CU), row-scan kernel between count and scatter
 
 template <class K, int ROUNDS>
