@@ -497,46 +497,23 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     const int total = nrows * 27;
     unsigned myhits = 0u;
     auto off_grid = [&](int v) { return POW2 ? (v & (parent_pitch - 1)) != 0 : (v % parent_pitch) != 0; };
-    // A thread's (up to) 7 probes are issued TOGETHER: first the first slot's key AND value of every probe (the value load
-    // does not wait for the key: a slot's value is only used when its key matches), then the compares.  One probe at a time —
-    // key, compare, value, store, next probe — left every lane with a single load in flight: with the chip's 32 waves per CU
-    // that is 2,048 loads per CU against a ~1 us round trip, and a map of 11.9 M rows took the same 1.6-1.7 ms with 27
-    // probes per row (same set) and with 3.4 (transposed): latency, not bytes (round-4 counters: the waves wait 68 % of their
-    // cycles, the vector L1 hits 96 %).  A first slot that holds another key (table_find's lane walk) is rare at load <= 1/2
-    // and takes the full search afterwards; lanes keep their offset-fastest mapping, so the stores stay coalesced.
-    constexpr int U = 7;                                     // 64 rows x 27 offsets = 1,728 pair slots = 6.75 per thread
-    uint64_t key[U], got[U];
-    uint32_t slot[U];
-    int val[U];
-    bool live[U];
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-        const int e = threadIdx.x + 256 * j;
-        const bool valid = e < total;
-        const int lr = valid ? e / 27 : 0, k = valid ? e - lr * 27 : 0;
+    // One probe at a time per lane.  Round-4 counters on an 11.9 M-row set (profiles/r04_kernel_map_counters.txt): a wave
+    // lives 18.5 us and issues 34 vector loads one after the other (~0.55 us each), waiting 68 % of its cycles, at the chip's
+    // full 8 waves per SIMD; the vector L1 hits 96 %.  The same map TRANSPOSED (an eighth of the probes, the same number of
+    // wave-level load instructions, the same TCP_TOTAL_ACCESSES) takes the same 1.6 ms — the cost is per wave instruction,
+    // not per probe.  Issuing a thread's seven probes together (key and value of every first slot at once, compares after:
+    // 14 loads in flight per lane) measured SLOWER, 2.18 ms against 1.74 (twice: round 3's and round 4's form of it): more
+    // load instructions (values of missing neighbours, restarted searches) through the same per-instruction bottleneck.
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int lr = e / 27, k = e - lr * 27;
         const int4 c = rows[lr];
         const int4 o = offs[k];
         const int x = c.y + o.x, y = c.z + o.y, z = c.w + o.z;
-        live[j] = valid && (parent_pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z)));
-        key[j] = pack_key(c.x, x, y, z);
-        slot[j] = (uint32_t)table_slot0(key[j], mask, shift);
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-        got[j] = live[j] ? keys[slot[j]] : KEY_EMPTY;
-        val[j] = live[j] ? vals[slot[j]] : -1;
-    }
-#pragma unroll
-    for (int j = 0; j < U; ++j) {
-        const int e = threadIdx.x + 256 * j;
-        if (e >= total) continue;
         int idx = -1;
-        if (live[j]) {
-            if (got[j] == key[j]) idx = val[j];
-            else if (got[j] != KEY_EMPTY) idx = table_find(keys, vals, mask, shift, key[j]);      // cold: the first slot is another key's
-        }
+        if (parent_pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z)))
+            idx = table_find(keys, vals, mask, shift, pack_key(c.x, x, y, z));
         nbr[row0 * 27 + e] = idx;
-        if (idx >= 0) { atomicOr(&rm[e / 27], 1u << (e % 27)); ++myhits; }
+        if (idx >= 0) { atomicOr(&rm[lr], 1u << k); ++myhits; }
     }
     if (myhits) atomicAdd(&hits_s, myhits);
     __syncthreads();
