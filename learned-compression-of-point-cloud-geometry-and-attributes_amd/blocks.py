@@ -110,6 +110,46 @@ def prefetch_up_maps(x_map):
     x_map._cache[key] = True
 
 
+def prefetch_analysis_maps(x_map, levels=5, hyper_ups=2):
+    """The encoder's counterpart: every coordinate set below ``x_map`` (stride-2 sets down to the hyper-latents') and every
+    kernel map and execution order of g_a, h_a and h_s are pure functions of the input coordinates.  Built on the side stream
+    while the main stream runs the first full-resolution layers (which the caller has already enqueued), instead of one by
+    one in front of the layers that use them — ~25 launches and seven count reads per frame, most of them one-workgroup
+    kernels of 30-100 us on sets the chip cannot be filled with.  Inference path only; joined by ``_join_prefetch(x_map)``."""
+    if os.environ.get("PCC_PREFETCH_MAPS", "1") == "0" or torch.is_grad_enabled():
+        return
+    key = ("analysis_prefetched",)
+    if x_map._cache.get(key):
+        return
+    dev = x_map.device
+    main = torch.cuda.current_stream(dev)
+    skey = (dev, main.cuda_stream)
+    side = _SIDE_STREAMS.get(skey)
+    if side is None:
+        side = _SIDE_STREAMS[skey] = torch.cuda.Stream(device=dev)
+    x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        m, sets = x_map, [x_map]
+        for _ in range(levels):
+            d = m.down()
+            m.mfma_kernel_map(d, 3)                          # the stride-2 convolution onto the coarser set
+            d.mfma_kernel_map(d, 3)                          # the stride-1 convolutions on it
+            sets.append(d)
+            m = d
+        y_map = sets[3] if len(sets) > 3 else None           # stride 8: the latents' set; h_s ends on it
+        u = m
+        for _ in range(hyper_ups if y_map is not None and levels >= 5 else 0):
+            c = u.up(2)                                      # h_s: generative transposed convolutions, kernel 2
+            u.mfma_kernel_map(c, 2, True)
+            c.mfma_kernel_map(c, 3)
+            u = c
+        if y_map is not None and u is not m:
+            u.mfma_kernel_map(y_map, 3)                      # h_s's last layer, evaluated at the latents' coordinates
+        x_map._cache[("prefetch_event",)] = side.record_event()
+    x_map._cache[key] = True
+
+
 def _join_prefetch(x_map):
     ev = x_map._cache.pop(("prefetch_event",), None)
     if ev is not None:

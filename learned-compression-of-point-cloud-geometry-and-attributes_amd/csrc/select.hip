@@ -90,8 +90,18 @@ __global__ __launch_bounds__(256) void topk_hist(const float* __restrict__ logit
         const Key96 key = make_key(logits[i * ld], c);
         if (cmp_prefix(key, st, pass) != 0) continue;
         const uint32_t digit = (key.w[pass >> 2] >> (8 * (3 - (pass & 3)))) & 0xFFu;
-        if (use_lds) atomicAdd(&lh[b * 256 + digit], 1);
-        else atomicAdd(&state[(int64_t)b * TK_STRIDE + 8 + digit], 1);
+        if (use_lds && nbatch == 1) {
+            // Occupancy logits of one frame share their sign and exponent: in the first passes nearly every row of a wave
+            // falls into the same one or two bins, and 64 LDS atomics on one address serialise.  The lanes of a wave that
+            // hold the same digit are found with ballots (match_digit) and ONE lane adds their count.  (The lanes that skipped
+            // this row above take no part in the ballots: the loop runs with the wave's current exec mask.)
+            const uint64_t same = match_digit(digit, true);
+            if ((same & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicAdd(&lh[digit], __popcll(same));
+        } else if (use_lds) {
+            atomicAdd(&lh[b * 256 + digit], 1);
+        } else {
+            atomicAdd(&state[(int64_t)b * TK_STRIDE + 8 + digit], 1);
+        }
     }
     if (use_lds) {
         __syncthreads();

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import sparse as sp
-from .blocks import prefetch_up_maps, ConditionEncoder, GenerativeUpBlock, ScaledBlock, _conv
+from .blocks import _join_prefetch, prefetch_analysis_maps, prefetch_up_maps, ConditionEncoder, GenerativeUpBlock, ScaledBlock, _conv
 from .sparse import ConvChain, CoordMap, MinkowskiConvolution, MinkowskiReLU, SparseTensor
 
 
@@ -65,9 +65,14 @@ class AnalysisTransform(nn.Module):
                 Q = SparseTensor(Q.F + Q_plus.F, coordinate_map=x.map)
             else:
                 Q = SparseTensor(Q.F + Q_plus.features_at_coordinates(Q.C), coordinate_map=Q.map)
+        x_in_map = x.map
+        x = self.pre_conv(x)               # (before the condition encoder: the same values in either order — the full-resolution layers
+        #                                    are what the main stream runs while the side stream builds every coarser set and map)
+        if Q.map is x_in_map:
+            prefetch_analysis_maps(x_in_map)
+            _join_prefetch(x_in_map)
         Q, beta_gammas = self.condition_encoder(Q)
 
-        x = self.pre_conv(x)
         x = self.down_1(x)
         x = self.scale_1(x, beta_gammas[0])
         k.append(self.count_per_batch(x))
