@@ -481,12 +481,15 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     __shared__ int4 offs[27];
     __shared__ unsigned rm[64];
     __shared__ unsigned hits_s;
+    __shared__ unsigned short queue[64 * 27];      // pair slots whose first table slot holds another key (phase B)
+    __shared__ int queue_n;
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     if (threadIdx.x < 64) {
         const int64_t r = row0 + threadIdx.x;
         rows[threadIdx.x] = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
         rm[threadIdx.x] = 0u;
     }
+    if (threadIdx.x == 255) queue_n = 0;
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) {
         const int k = threadIdx.x - 64;
         offs[k] = make_int4((k % 3 - 1) * step, ((k / 3) % 3 - 1) * step, (k / 9 - 1) * step, 0);
@@ -497,21 +500,89 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     const int total = nrows * 27;
     unsigned myhits = 0u;
     auto off_grid = [&](int v) { return POW2 ? (v & (parent_pitch - 1)) != 0 : (v % parent_pitch) != 0; };
-    // One probe at a time per lane.  Round-4 counters on an 11.9 M-row set (profiles/r04_kernel_map_counters.txt): a wave
-    // lives 18.5 us and issues 34 vector loads one after the other (~0.55 us each), waiting 68 % of its cycles, at the chip's
-    // full 8 waves per SIMD; the vector L1 hits 96 %.  The same map TRANSPOSED (an eighth of the probes, the same number of
-    // wave-level load instructions, the same TCP_TOTAL_ACCESSES) takes the same 1.6 ms — the cost is per wave instruction,
-    // not per probe.  Issuing a thread's seven probes together (key and value of every first slot at once, compares after:
-    // 14 loads in flight per lane) measured SLOWER, 2.18 ms against 1.74 (twice: round 3's and round 4's form of it): more
-    // load instructions (values of missing neighbours, restarted searches) through the same per-instruction bottleneck.
-    for (int e = threadIdx.x; e < total; e += 256) {
+    // Two phases (round 4; profiles/r04_kernel_map_counters.txt).  The one-probe-at-a-time loop this replaces left every lane with
+    // a single load in flight: a wave lived 18.5 us and issued 34 loads one after the other, each waiting for the slowest of its
+    // ~25 lines (0.5 us: one of them misses the L2 nearly always), 68 % of all wave cycles spent waiting; the same map TRANSPOSED
+    // — an eighth of the probes — took the same 1.6 ms on 11.9 M rows.  Batching alone (round 3, and again in round 4) was
+    // SLOWER: one probe in five finds another key in its first slot, so in every wave SOME lane needs the lane walk, and the
+    // wave pays that dependent chain once per batched probe.
+    //   A: the first slot's key and value of all (up to) seven probes of a thread are loaded together; a match or an empty slot
+    //      settles the probe, anything else goes to a queue in LDS;
+    //   B: the workgroup's queued probes (~ a fifth) are taken up DENSELY, a lane each, with the next four slots of the lane walk
+    //      (keys and values) loaded together; what is still open after five slots (~0.5 %) finishes with the sequential search.
+    // The table walk is table_find's, slot for slot, so the map is the same.  Measured (tools/coord_bench.py, 11.9 M rows): same-set
+    // map 1.74 -> 1.47 ms, transposed 1.58 -> 1.17 ms.  What is left is vector-ALU issue, not memory: ~670 vector instructions
+    // per wave (hash with four quarter-rate 32-bit multiplies, 64-bit keys and addresses, the exec-mask bookkeeping of seven
+    // unrolled probes) x 4 cycles per wave64 instruction on a 16-lane SIMD x 726 waves per SIMD = 0.93 ms of the 1.17; dropping
+    // every value load (an ablation build) took only another 10 % off.  The next step would share one hash between the three dz
+    // probes of a (dx, dy) column — a lane per column, results transposed through LDS; not built.
+    constexpr int U = 7;                                     // 64 rows x 27 offsets = 1,728 pair slots = 6.75 per thread
+    {
+        uint64_t key[U], got[U];
+        uint32_t slot[U];
+        int val[U];
+        bool live[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            const bool valid = e < total;
+            const int lr = valid ? e / 27 : 0, k = valid ? e - lr * 27 : 0;
+            const int4 c = rows[lr];
+            const int4 o = offs[k];
+            const int x = c.y + o.x, y = c.z + o.y, z = c.w + o.z;
+            live[j] = valid && (parent_pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z)));
+            key[j] = pack_key(c.x, x, y, z);
+            slot[j] = (uint32_t)table_slot0(key[j], mask, shift);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            got[j] = live[j] ? keys[slot[j]] : KEY_EMPTY;
+            val[j] = live[j] ? vals[slot[j]] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int e = threadIdx.x + 256 * j;
+            if (e >= total) continue;
+            int idx = -1;
+            if (live[j] && got[j] != KEY_EMPTY) {
+                if (got[j] == key[j]) idx = val[j];
+                else {                                       // another key's: the lane walk, in phase B
+                    queue[atomicAdd(&queue_n, 1)] = (unsigned short)e;
+                    continue;
+                }
+            }
+            nbr[row0 * 27 + e] = idx;
+            if (idx >= 0) { atomicOr(&rm[e / 27], 1u << (e % 27)); ++myhits; }
+        }
+    }
+    __syncthreads();
+    const int qn = queue_n;
+    for (int qi = threadIdx.x; qi < qn; qi += 256) {
+        const int e = queue[qi];
         const int lr = e / 27, k = e - lr * 27;
         const int4 c = rows[lr];
         const int4 o = offs[k];
-        const int x = c.y + o.x, y = c.z + o.y, z = c.w + o.z;
+        const uint64_t key = pack_key(c.x, c.y + o.x, c.z + o.y, c.w + o.z);
+        const uint64_t slot0 = table_slot0(key, mask, shift);
+        uint64_t kk[4];
+        int vv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint64_t sl = (slot0 + (uint64_t)(i + 1) * TABLE_PROBE_STEP) & mask;
+            kk[i] = keys[sl];
+            vv[i] = vals[sl];
+        }
         int idx = -1;
-        if (parent_pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z)))
-            idx = table_find(keys, vals, mask, shift, pack_key(c.x, x, y, z));
+        bool open = true;
+        const int lane_slots = (int)((mask + TABLE_PROBE_STEP) / TABLE_PROBE_STEP);      // slots of a lane: the walk ends there
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (!open) break;
+            if (i + 1 >= lane_slots) break;                   // (tables of fewer than 40 slots: leave it to the search below)
+            if (kk[i] == key) { idx = vv[i]; open = false; }
+            else if (kk[i] == KEY_EMPTY) { idx = -1; open = false; }
+        }
+        if (open) idx = table_find(keys, vals, mask, shift, key);     // cold: five slots of the lane taken by other keys
         nbr[row0 * 27 + e] = idx;
         if (idx >= 0) { atomicOr(&rm[lr], 1u << k); ++myhits; }
     }
