@@ -1036,6 +1036,7 @@ def main():
         cb = (prev or {}).get("cpu_baseline")
         if cb:
             cb = dict(cb)
+            cb.setdefault("cpu_model", None)                 # records of rounds 1-3 did not name the CPU
             cb["replayed_from"] = {"file": prev["_file"], "commit": prev.get("commit"),
                                    "note": "measured by the N = 1 run of this command on one MI355X box's host cores; not re-measured in this run"}
         out["cpu_baseline"] = cb

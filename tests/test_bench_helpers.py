@@ -62,3 +62,26 @@ def test_kernel_source_hash_covers_the_coordinate_side_too():
     the convolution kernel: all of them are in the staleness stamp"""
     import bench
     assert {"conv.hip", "common.h", "coords.hip", "sort.hip", "select.hip", "sort.h", "sort_small.h"} <= set(bench.KERNEL_SOURCES)
+
+
+def test_visible_gpu_count_reads_the_environment_not_the_runtime(monkeypatch):
+    """the launcher of `--gpus N` counts devices without touching the HIP runtime: the visible-devices variables
+    decide when set; this container has no GPU nodes in /sys/class/kfd"""
+    import bench
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    base = bench.visible_gpu_count()
+    assert base >= 0
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench.visible_gpu_count() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    name = bench.cpu_model_name()
+    assert name is None or (isinstance(name, str) and name)
+
+
+def test_n_gt_1_line_carries_the_committed_cpu_baseline():
+    """bench.py at N > 1 replays cpu_baseline from the newest committed N = 1 record: that record must exist and hold one"""
+    import bench
+    prev = bench.latest_profile("bench_config2")
+    assert prev is not None and prev.get("cpu_baseline") and prev["cpu_baseline"]["value"] > 0 and prev["cpu_baseline"]["cores"] >= 1

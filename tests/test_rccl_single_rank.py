@@ -87,6 +87,15 @@ def test_bench_starts_its_own_two_ranks():
     assert line["config"]["parallelism"] == "frames x2"
     assert line["blocks"]["decoded_points"] == line["blocks"]["points_per_frame"]
     assert sum(line["blocks"]["cubes_per_rank"]) == line["blocks"]["cubes"] and min(line["blocks"]["cubes_per_rank"]) > 0
+    # an N > 1 line is as complete as the N = 1 line: the roofline of the dominant class measured in this run,
+    # the CPU baseline carried from the newest committed N = 1 record (labelled as replayed), every rank's own step time
+    assert line["roofline"] is not None and line["roofline"]["bound"] == "mfma" and line["roofline"]["achieved"] > 0
+    cb = line["cpu_baseline"]
+    assert cb is not None and cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port" and "replayed_from" in cb
+    assert cb["replayed_from"]["file"].startswith("profiles/r") and "cpu_model" in cb
+    assert all(d["ms_per_step"] > 0 for d in line["rccl"]["devices"])
+    lo, hi = line["rccl"]["ms_per_step_min_max_over_ranks"]
+    assert 0 < lo <= hi
 
 
 def test_bench_refuses_more_ranks_than_gpus():
