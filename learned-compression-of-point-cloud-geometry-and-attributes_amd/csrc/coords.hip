@@ -477,8 +477,11 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
                                                            int step, int parent_pitch, int32_t* __restrict__ nbr,
                                                            uint32_t* __restrict__ row_mask,
                                                            unsigned long long* __restrict__ pair_count) {
-    __shared__ int4 rows[64];
-    __shared__ int4 offs[27];
+    // A neighbour's key is the row's key plus a constant: every field of a voxel key stays inside its 16 bits under a step of
+    // one stride (COORD_LIMIT's margin, common.h), so the 64-bit sum of the row's key and the offset's packed delta IS
+    // pack_key(b, x + dx step, y + dy step, z + dz step) — one add per probe instead of three coordinate adds and a pack.
+    __shared__ uint64_t rowkey[64];
+    __shared__ uint64_t dkey[27];
     __shared__ unsigned rm[64];
     __shared__ unsigned hits_s;
     __shared__ unsigned short queue[64 * 27];      // pair slots whose first table slot holds another key (phase B)
@@ -486,20 +489,32 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     const int64_t row0 = (int64_t)blockIdx.x * 64;
     if (threadIdx.x < 64) {
         const int64_t r = row0 + threadIdx.x;
-        rows[threadIdx.x] = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
+        const int4 c = (r < n_out) ? reinterpret_cast<const int4*>(out_coords)[r] : make_int4(0, 0, 0, 0);
+        rowkey[threadIdx.x] = pack_key(c.x, c.y, c.z, c.w);
         rm[threadIdx.x] = 0u;
     }
     if (threadIdx.x == 255) queue_n = 0;
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) {
         const int k = threadIdx.x - 64;
-        offs[k] = make_int4((k % 3 - 1) * step, ((k / 3) % 3 - 1) * step, (k / 9 - 1) * step, 0);
+        const int64_t dx = (int64_t)(k % 3 - 1) * step, dy = (int64_t)((k / 3) % 3 - 1) * step, dz = (int64_t)(k / 9 - 1) * step;
+        dkey[k] = (uint64_t)(dx * (1ll << 32) + dy * (1ll << 16) + dz);
     }
     if (threadIdx.x == 0) hits_s = 0u;
     __syncthreads();
     const int nrows = (int)((n_out - row0 < 64) ? (n_out - row0) : 64);
     const int total = nrows * 27;
     unsigned myhits = 0u;
-    auto off_grid = [&](int v) { return POW2 ? (v & (parent_pitch - 1)) != 0 : (v % parent_pitch) != 0; };
+    // transposed maps: the parent must lie on the grid of pitch 2 step; COORD_BIAS is a multiple of every power-of-two pitch,
+    // so the test reads the biased fields of the key directly
+    auto off_grid_key = [&](uint64_t key) {
+        const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        if (POW2) {
+            const uint32_t m = (uint32_t)(parent_pitch - 1);
+            return (((lo | (lo >> 16) | hi) & m) != 0u);
+        }
+        const int z = (int)(lo & 0xFFFFu) - COORD_BIAS, y = (int)(lo >> 16) - COORD_BIAS, x = (int)(hi & 0xFFFFu) - COORD_BIAS;
+        return (x % parent_pitch) != 0 || (y % parent_pitch) != 0 || (z % parent_pitch) != 0;
+    };
     // Two phases (round 4; profiles/r04_kernel_map_counters.txt).  The one-probe-at-a-time loop this replaces left every lane with
     // a single load in flight: a wave lived 18.5 us and issued 34 loads one after the other, each waiting for the slowest of its
     // ~25 lines (0.5 us: one of them misses the L2 nearly always), 68 % of all wave cycles spent waiting; the same map TRANSPOSED
@@ -522,26 +537,33 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
         uint32_t slot[U];
         int val[U];
         bool live[U];
+        // pair slot e = threadIdx.x + 256 j = 27 lr + k: from one j to the next lr advances by 9 and k by 13 (256 = 9 x 27 + 13)
+        int lr = threadIdx.x / 27, k = threadIdx.x - lr * 27;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int e = threadIdx.x + 256 * j;
             const bool valid = e < total;
-            const int lr = valid ? e / 27 : 0, k = valid ? e - lr * 27 : 0;
-            const int4 c = rows[lr];
-            const int4 o = offs[k];
-            const int x = c.y + o.x, y = c.z + o.y, z = c.w + o.z;
-            live[j] = valid && (parent_pitch <= 0 || !(off_grid(x) || off_grid(y) || off_grid(z)));
-            key[j] = pack_key(c.x, x, y, z);
+            key[j] = rowkey[valid ? lr : 0] + dkey[k];
+            live[j] = valid && (parent_pitch <= 0 || !off_grid_key(key[j]));
             slot[j] = (uint32_t)table_slot0(key[j], mask, shift);
+            lr += 9;
+            k += 13;
+            if (k >= 27) { k -= 27; ++lr; }
         }
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             got[j] = live[j] ? keys[slot[j]] : KEY_EMPTY;
             val[j] = live[j] ? vals[slot[j]] : -1;
         }
+        lr = threadIdx.x / 27;
+        k = threadIdx.x - lr * 27;
 #pragma unroll
         for (int j = 0; j < U; ++j) {
             const int e = threadIdx.x + 256 * j;
+            const int lr_j = lr, k_j = k;
+            lr += 9;
+            k += 13;
+            if (k >= 27) { k -= 27; ++lr; }
             if (e >= total) continue;
             int idx = -1;
             if (live[j] && got[j] != KEY_EMPTY) {
@@ -552,7 +574,7 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
                 }
             }
             nbr[row0 * 27 + e] = idx;
-            if (idx >= 0) { atomicOr(&rm[e / 27], 1u << (e % 27)); ++myhits; }
+            if (idx >= 0) { atomicOr(&rm[lr_j], 1u << k_j); ++myhits; }
         }
     }
     __syncthreads();
@@ -560,9 +582,7 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     for (int qi = threadIdx.x; qi < qn; qi += 256) {
         const int e = queue[qi];
         const int lr = e / 27, k = e - lr * 27;
-        const int4 c = rows[lr];
-        const int4 o = offs[k];
-        const uint64_t key = pack_key(c.x, c.y + o.x, c.z + o.y, c.w + o.z);
+        const uint64_t key = rowkey[lr] + dkey[k];
         const uint64_t slot0 = table_slot0(key, mask, shift);
         uint64_t kk[4];
         int vv[4];
