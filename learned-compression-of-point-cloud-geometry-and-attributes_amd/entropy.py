@@ -6,7 +6,8 @@ same constructor arguments, parameter / buffer names (so reference state_dicts l
 ``compress`` / ``decompress`` / ``forward`` / ``update`` / ``loss`` methods.  Quantisation, index
 build and likelihoods run as HIP kernels on [N, C] feature matrices; CDF tables are built on the
 host at ``update()`` (one-off) and the rANS coder is the host C++ one in the same library
-(SURVEY.md N12-N14).  Training-mode (additive noise, gradients) is not implemented.
+(SURVEY.md N12-N14).  Training mode — additive U(-.5, .5) noise instead of rounding, likelihoods differentiable through torch
+ops, compressai's LowerBound gradients — is ``forward(..., training=True)`` / ``module.train()``.
 """
 import math
 

@@ -1,7 +1,9 @@
 """CPU oracle for the joint geometry+attribute point-cloud codec hot path.
 
 TEST INFRASTRUCTURE ONLY.  This package is a CPU restatement (numpy integer
-arithmetic + torch-CPU fp32 matmuls + a small C rANS coder) of the algorithm in
+arithmetic + torch-CPU fp32 matmuls + a small C rANS coder; and, as a second
+summation order, chain.c: every convolution as one fused multiply-add chain per
+output element in the order the product's kernels document — nn.set_order) of the algorithm in
 the reference's ``model/{model,transforms,blocks,entropy_models}.py`` and of the
 third-party operator semantics it relies on (MinkowskiEngine 0.5.4 — version
 unpinned upstream — and compressai 1.2.4, neither present under /root/reference
@@ -28,4 +30,11 @@ Bjontegaard_Model / Bjontegaard_Delta, NOT the codec:
 the codec's arithmetic stays "parity unpinned" — that is the environment's
 limit (no MinkowskiEngine / compressai), and no stand-in modules are written to
 get around it.
+
+The "kernel" summation order (oracle/chain.c, round 4) does not change that status: it
+states the arithmetic the PRODUCT documents, so equality with it (tests/test_exact_parity.py:
+streams, latents, voxels, colours, up to the full config-2 frame) shows the HIP path computes
+exactly what it says on every layer and tile shape — a self-consistency check as strong as a
+check can be — while the claim "this is MinkowskiEngine's / compressai's arithmetic" rests on
+the BLAS-order restatement and stays unpinned.
 """
