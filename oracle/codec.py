@@ -63,8 +63,10 @@ def prune_by_coords(x, keep_coords):
     return on.prune(x, mask)
 
 
-def up_block_predict(p, x, k, dense=True, condition_ablation=None):
-    """blocks.py:152-177, predict=True; dense=False (:168-175) predicts on the raw candidates and refines the kept rows."""
+def up_block_predict(p, x, k, dense=True, condition_ablation=None, full_predictions=False):
+    """blocks.py:152-177, predict=True; dense=False (:168-175) predicts on the raw candidates and refines the kept rows.
+    ``full_predictions``: the caller returns the whole occupancy tensor (model.py:88, the training / eval forward) — the product then
+    evaluates all its columns as one wide layer; otherwise (compress / decompress) only column 0 is ever read (blocks.py:142)."""
     def conv_2(t):
         h = on.relu(p.sub("conv_2").conv(t, "0"))
         return p.sub("conv_2").conv(h, "2")
@@ -74,7 +76,8 @@ def up_block_predict(p, x, k, dense=True, condition_ablation=None):
     h = p.sub("occ_predict").conv(x, "0")
     h = on.relu(h)
     # only channel 0 is ever read (blocks.py:142); in "kernel" order it is evaluated the way the product evaluates it: alone
-    pred = p.sub("occ_predict").conv(h, "2", out_channels=1 if on.ORDER == "kernel" else None)
+    # (a narrow head) in compress / decompress, as a column of the wide layer where the forward pass returns the whole tensor
+    pred = p.sub("occ_predict").conv(h, "2", out_channels=1 if (on.ORDER == "kernel" and not full_predictions) else None)
     mask = topk_mask(pred, k)
     up_coords = pred.C[mask]
     x = prune_by_coords(x, up_coords)
@@ -148,7 +151,8 @@ def synthesis(p, x, Q, k, coords=None, cfg=None):
         qq = p.sub(f"q_predict_{i}")
         bg = qq.conv(on.relu(qq.conv(on.relu(qq.conv(Q, "0")), "2")), "4")
         x = scaled_block(p.sub(f"scale_{i}"), x, bg)
-        x, pred, up_coords = up_block_predict(p.sub(f"up_{i}"), x, k[i - 1], dense=cfg.get("dense", True))
+        x, pred, up_coords = up_block_predict(p.sub(f"up_{i}"), x, k[i - 1], dense=cfg.get("dense", True),
+                                              full_predictions=coords is not None)
         Q = up_block_follow(p.sub(f"q_up_{i}"), Q, up_coords)
         preds.append(pred)
     pc = p.sub("post_conv")

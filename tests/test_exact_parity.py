@@ -155,3 +155,43 @@ def test_full_config2_frame_equals_the_kernel_order_oracle(pcc, model, oracle_co
     assert pts.shape[0] == 850_824
     qc, qf = syn.uniform_qmap(pts[:, :3], 0.5, 0.5)
     exact_compare(pcc, model, oracle_codec, pts, qc, qf, "config 2, full size")
+
+
+@pytest.mark.parametrize("cfg", [dict(grid=32, radius=15.0, half_width=0.875), dict(grid=64, radius=27.0, half_width=0.6)])
+def test_eval_forward_tensors_equal_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order, cfg):
+    """ColorModel.forward in eval mode (model/model.py:51-93): everything it returns that is convolution arithmetic — the
+    reconstruction's features, the three occupancy-logit tensors on their candidate sets, the coordinate pyramids — EQUAL to the
+    kernel-order oracle's, value for value, after a canonical sort of both sides (tests/test_hip_codec.py compares the same tensors
+    with the BLAS-order oracle at rtol 1e-4).  The likelihood tensors pass through erfc / exp / tanh, which the two sides take from
+    different math libraries: their total bits agree to 1e-6 relative, and the quantised latents they are evaluated at are equal."""
+    pts = pcc.synthetic.sphere_shell(**cfg)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    N = pts.shape[0]
+    coords = np.concatenate([np.zeros((N, 1)), pts[:, :3]], axis=1).astype(np.int32)
+    x = pcc.SparseTensor(coordinates=torch.from_numpy(coords).to(DEV), features=torch.from_numpy(pts[:, 3:6]).to(DEV))
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    with torch.no_grad():
+        out = model(x, Q, None)
+    ref = oracle_codec.forward_eval(coords, pts[:, 3:6], qc, qf)
+
+    def sorted_rows(C, F):
+        C = np.asarray(C.cpu() if torch.is_tensor(C) else C)
+        F = (F.detach().cpu() if torch.is_tensor(F) else torch.as_tensor(F)).numpy()
+        o = oc.sort_order(C)
+        return C[o], F[o]
+
+    for i, (p_got, p_ref) in enumerate(zip(out["occ_predictions"], ref["occ_predictions"])):
+        cg, fg = sorted_rows(p_got.C, p_got.F)
+        cr, fr = sorted_rows(p_ref.C, p_ref.F)
+        assert np.array_equal(cg, cr), (cfg, "candidate set", i)
+        assert np.array_equal(fg[:, 0], fr[:, 0]), (cfg, "occupancy logits", i, int((fg[:, 0] != fr[:, 0]).sum()))
+    cg, fg = sorted_rows(out["prediction"].C, out["prediction"].F)
+    cr, fr = sorted_rows(ref["prediction"].C, ref["prediction"].F)
+    assert np.array_equal(cg, cr) and np.array_equal(fg, fr), (cfg, "prediction", int((fg != fr).sum()))
+    for p_got, p_ref in zip(out["points"], ref["points"]):
+        assert np.array_equal(sorted_rows(p_got.C, p_got.C)[0], np.asarray(p_ref)[oc.sort_order(np.asarray(p_ref))])
+    bits = lambda L: float(-torch.log2(L.double()).sum())
+    for key in ("y", "z"):
+        got, want = out["likelihoods"][key].cpu(), ref["likelihoods"][key]
+        assert got.shape == want.shape
+        assert abs(bits(got) - bits(want)) <= 1e-6 * bits(want) + 1e-3, (cfg, key, bits(got), bits(want))
