@@ -817,7 +817,7 @@ def main():
                 for k_ in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PCC_BENCH_FORCE_DIST", "PCC_BENCH_REHEARSE"):
                     env.pop(k_, None)
                 r_ = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), "--batch", "8", "--block", "256",
-                                     "--steps", "5", "--warmup", "3"], env=env, capture_output=True, text=True, timeout=420)
+                                     "--steps", "5", "--warmup", "3"], env=env, capture_output=True, text=True, timeout=150)
                 line = next((ln for ln in reversed(r_.stdout.splitlines()) if ln.lstrip().startswith("{")), None)
                 if r_.returncode != 0 or line is None:
                     train_record[tag] = {"error": (r_.stderr or r_.stdout)[-300:]}
