@@ -124,45 +124,6 @@ def _transposed_map(in_map, out_map, ksize, transposed):
     return res
 
 
-_SIDE_STREAMS = {}
-PREFETCH_BACKWARD_MAPS = os.environ.get("PCC_PREFETCH_MAPS", "1") != "0"
-
-
-def _prefetch_backward_maps(in_map, out_map, ksize, transposed, want_dx, want_dw):
-    """The maps only the backward pass reads — the transposed map with its execution order (backward-data) and the permuted
-    table the weight-gradient kernels index by position — are pure functions of the forward map.  Built on a side stream
-    while the main stream runs this layer's forward convolution (and every later one), instead of in front of the first
-    backward kernel that needs them: ~6 ms of map_transpose / radix / permute kernels per 812 k-point step.  One build per
-    (input set, output set, kernel): every layer on the same map shares it.  The backward pass waits for the event."""
-    if not PREFETCH_BACKWARD_MAPS or ksize == 1:
-        return
-    key = ("bwd_prefetch", id(out_map), ksize, transposed)
-    hit = in_map._cache.get(key)
-    if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is in_map)):
-        return
-    dev = in_map.device
-    main = torch.cuda.current_stream(dev)
-    skey = (dev, main.cuda_stream)
-    side = _SIDE_STREAMS.get(skey)
-    if side is None:
-        side = _SIDE_STREAMS[skey] = torch.cuda.Stream(device=dev)
-    in_map.kernel_map(out_map, ksize, transposed)          # (cached: the forward built it on the main stream)
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        if want_dx:
-            _transposed_map(in_map, out_map, ksize, transposed)
-        if want_dw:
-            in_map.position_ordered_table(out_map, ksize, transposed)
-        ev = side.record_event()
-    in_map._cache[key] = (None if out_map is in_map else out_map, ev)
-
-
-def _join_backward_maps(in_map, out_map, ksize, transposed):
-    hit = in_map._cache.get(("bwd_prefetch", id(out_map), ksize, transposed))
-    if hit is not None and (hit[0] is out_map or (hit[0] is None and out_map is in_map)):
-        torch.cuda.current_stream(in_map.device).wait_event(hit[1])
-
-
 class SparseConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, kernel, bias, in_map, out_map, ksize, transposed, out_channels):
@@ -178,7 +139,6 @@ class SparseConvFn(torch.autograd.Function):
         nbr, order, gmask = _forward_map(in_map, out_map, ksize, transposed, feats.shape[1])
         if _bf16_ok(feats.shape[0], feats.shape[1]):
             feats = feats.to(torch.bfloat16)          # the one cast of this tensor: forward now, weight gradient later
-        _prefetch_backward_maps(in_map, out_map, ksize, transposed, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         out = _launch_conv(feats, w, b, nbr, order, gmask, out_map.n)
         ctx.save_for_backward(feats, w)
         ctx.meta = (in_map, out_map, ksize, transposed, out_channels, tuple(kernel.shape), bias is not None)
@@ -194,7 +154,6 @@ class SparseConvFn(torch.autograd.Function):
         n_in, n_out = feats.shape[0], dy.shape[0]
         dev = dy.device
         d_feats = d_kernel = d_bias = None
-        _join_backward_maps(in_map, out_map, ksize, transposed)
         bf = feats.dtype == torch.bfloat16                 # forward ran in bf16: the saved input is the bf16 copy
         want_db = has_bias and ctx.needs_input_grad[2]
         # dY is read once for its bf16 copy (weight gradient, backward-data) and its column sums (bias gradient)
