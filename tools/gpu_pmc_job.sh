@@ -12,8 +12,10 @@ cd /tmp && export TMPDIR=/tmp
 pass() {   # name, counters...
   name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-blocks-record --no-x3-record --no-streamed-record --no-small-frame-record --no-mid-frame-record --no-train-record --no-hbm-record > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name.log 2>&1
-  echo "pmc $name rc=$?"
+  rc=$?
+  echo "pmc $name rc=$rc"
   rm -f $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name/*.db
+  return $rc                 # (the && chain below stops at the first failed pass: ADVICE r3)
 }
 pass FETCH_SIZE FETCH_SIZE && pass WRITE_SIZE WRITE_SIZE && pass GRBM_GUI_ACTIVE GRBM_GUI_ACTIVE && \
 pass MFMA_BUSY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE && pass MFMA_OPS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CYCLES && \
