@@ -32,7 +32,11 @@ def rgb_to_yuv(rgb):
 
 def _dedupe(pc):
     pts = pc[:, :3]
-    _, first = np.unique(pts, axis=0, return_index=True)
+    if pts.size and np.all(pts == np.floor(pts)) and np.abs(pts).max() < (1 << 20):      # integer grids: packed keys (np.unique over rows is 10x slower)
+        c = pts.astype(np.int64) + (1 << 20)
+        _, first = np.unique((c[:, 0] << 42) | (c[:, 1] << 21) | c[:, 2], return_index=True)
+    else:
+        _, first = np.unique(pts, axis=0, return_index=True)
     return pc[np.sort(first)]
 
 
@@ -43,15 +47,28 @@ def _one_way(a, b, resolution, average_ties=False, kmax=32):
     distance the colour becomes (first + sum of all of them) / (count + 1)."""
     tree = cKDTree(b[:, :3])
     k = min(kmax, b.shape[0])
-    dist, cand = tree.query(a[:, :3], k=k)
-    if k == 1:
-        dist, cand = dist[:, None], cand[:, None]
-    d2c = np.rint(dist ** 2).astype(np.int64)                      # integer grids: exact squared distances
-    best = d2c[:, :1]
-    tie = d2c == best
     bkey = (b[:, 0].astype(np.int64) << 42) + (b[:, 1].astype(np.int64) << 21) + b[:, 2].astype(np.int64)
-    ck = np.where(tie, bkey[cand], np.iinfo(np.int64).max)
-    nn = cand[np.arange(a.shape[0]), ck.argmin(axis=1)]
+
+    def resolve(q, kk):
+        dist, cand = tree.query(q, k=kk, workers=-1)              # all host cores: the same neighbours, found in parallel
+        if kk == 1:
+            dist, cand = dist[:, None], cand[:, None]
+        d2c = np.rint(dist ** 2).astype(np.int64)                  # integer grids: exact squared distances
+        tie = d2c == d2c[:, :1]
+        ck = np.where(tie, bkey[cand], np.iinfo(np.int64).max)
+        return cand, tie, cand[np.arange(q.shape[0]), ck.argmin(axis=1)]
+
+    if average_ties or k <= 2:
+        cand, tie, nn = resolve(a[:, :3], k)
+    else:
+        # two neighbours first: a point whose nearest neighbour is unique (nearly every point of a codec's output) is settled;
+        # only the points whose two nearest are equidistant need the whole tie set (up to kmax candidates) — the same choice
+        cand2, tie2, nn = resolve(a[:, :3], 2)
+        again = np.nonzero(tie2[:, 1])[0]
+        if again.size:
+            _, _, nn_again = resolve(a[again, :3], k)
+            nn[again] = nn_again
+        cand = tie = None
     d = ((a[:, :3] - b[nn, :3]) ** 2).mean(axis=1)
     res = {"mse": d.mean(), "hausdorff": d.max()}
     res["psnr_mse"] = 10 * np.log10(resolution ** 2 / res["mse"]) if res["mse"] > 0 else np.inf

@@ -51,8 +51,11 @@ def flip_bound_db(n_flips, n_points, mse, worst_sq):
 
 
 def voxel_flips(rec, o_rec):
-    a, b = set(map(tuple, rec[:, :3].tolist())), set(map(tuple, o_rec[:, :3].tolist()))
-    return len(a ^ b)
+    """voxels that are in one decoded set and not in the other"""
+    def keys(r):
+        c = np.asarray(r)[:, :3].astype(np.int64)
+        return np.unique(((c[:, 0] + (1 << 20)) << 42) | ((c[:, 1] + (1 << 20)) << 21) | (c[:, 2] + (1 << 20)))
+    return int(np.setxor1d(keys(rec), keys(o_rec), assume_unique=True).size)
 
 
 def assert_psnr_parity(m, om, flips, n_points, tag=None):
