@@ -98,6 +98,7 @@ def build(force=False):
         subprocess.check_call(args + ["clean"])
     subprocess.check_call(args)
     check_kernel_resources()
+    check_small_kernel_lds_reads()
     return SO_PATH
 
 
@@ -105,6 +106,82 @@ def build(force=False):
 # conv_small_kernel's inline-assembly LDS reads sit behind a hand-placed s_waitcnt that the compiler does not see: a spilled
 # or copied operand register would be read before its data has landed, silently)
 NO_SCRATCH_KERNELS = ("conv_small_kernel", "conv_mfma_buf_kernel", "conv_mfma_kernel")
+
+
+def check_small_kernel_lds_reads(obj=None):
+    """conv_small_kernel reads its MFMA operands with inline-assembly ds_read_b128, which the compiler does not count in
+    lgkmcnt; the kernel waits for them with a hand-placed s_waitcnt (csrc/conv.hip, pick()).  That is correct only while no
+    instruction touches a destination register of such a read between the read and the wait — a register copy or spill the
+    compiler inserted there would move stale data, silently.  This lints the generated code: the device code object
+    is extracted from build/conv.o, disassembled, and every conv_small_kernel instantiation is walked; any mention of a pending
+    read's registers before the next `s_waitcnt lgkmcnt(0)` fails the build.  -> number of reads checked."""
+    import glob
+    import re
+    import shutil
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    obj = obj or os.path.join(_HERE, "build", "conv.o")
+    if not os.path.exists(objdump) or not os.path.exists(obj):
+        raise RuntimeError(f"cannot lint conv_small_kernel: {objdump} or {obj} is missing")
+    tmp = os.path.join(_HERE, "build", "_lint")
+    shutil.rmtree(tmp, ignore_errors=True)
+    os.makedirs(tmp)
+    local = os.path.join(tmp, "conv.o")
+    shutil.copy(obj, local)
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=tmp)
+    cos = [f for f in glob.glob(local + ".*") if "amdgcn" in f]
+    if not cos:
+        raise RuntimeError("cannot lint conv_small_kernel: no device code object in build/conv.o")
+    dis = subprocess.run([objdump, "-d", cos[0]], check=True, capture_output=True, text=True).stdout
+    shutil.rmtree(tmp, ignore_errors=True)
+    return lint_lds_reads(dis)
+
+
+def lint_lds_reads(dis, kernel="conv_small_kernel"):
+    """the walk of check_small_kernel_lds_reads over a disassembly listing (llvm-objdump -d): -> reads checked, or RuntimeError"""
+    import re
+
+    def regs(operand):
+        m = re.fullmatch(r"v\[(\d+):(\d+)\]", operand)
+        if m:
+            return set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.fullmatch(r"v(\d+)", operand)
+        return {int(m.group(1))} if m else set()
+
+    checked, func, pending = 0, None, {}
+    for line in dis.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+        if m:
+            func = m.group(1) if kernel in m.group(1) else None
+            pending = {}
+            continue
+        if func is None:
+            continue
+        text = line.split("//")[0].strip()
+        if not text:
+            continue
+        parts = text.split(None, 1)
+        mnem = parts[0]
+        ops = [o.strip().split(" ")[0] for o in parts[1].split(",")] if len(parts) > 1 else []
+        if mnem == "s_waitcnt" and "lgkmcnt(0)" in text:
+            pending = {}
+            continue
+        touched = set()
+        for o in ops:
+            touched |= regs(o)
+        clash = touched & set(pending)
+        if mnem == "ds_read_b128":
+            dest = regs(ops[0])
+            clash = (touched - dest) & set(pending) | (dest & set(pending))
+            if not clash:
+                for r_ in dest:
+                    pending[r_] = text
+                checked += 1
+        if clash:
+            raise RuntimeError(f"{func}: `{text}` touches v{sorted(clash)} while an LDS read into them is still in flight "
+                               f"(`{pending[sorted(clash)[0]]}`): the hand-placed s_waitcnt of conv_small_kernel no longer covers it")
+    if not checked:
+        raise RuntimeError(f"cannot lint {kernel}: no ds_read_b128 found in its disassembly")
+    return checked
 
 
 def check_kernel_resources(path=None):

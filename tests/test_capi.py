@@ -72,3 +72,26 @@ def test_bench_uses_the_oracle_only_in_its_cpu_baseline_leg():
     rest = src.replace(body, "")
     assert "oracle" in body
     assert not re.search(r"^\s*(from|import)\s+oracle\b", rest, flags=re.M)
+
+
+def test_build_checks_of_the_convolution_kernels(pcc):
+    """build() fails when an MFMA convolution kernel uses scratch or spills (the compiler's resource remarks), and when the
+    code generated for conv_small_kernel touches a register an inline-assembly LDS read is still filling: both
+    checks pass on the built library, and the lint catches a planted violation"""
+    from pcc_amd import _lib
+    res = _lib.check_kernel_resources()
+    assert any("conv_small_kernel" in k for k in res) and all(v[1] in (0, None) for v in res.values())
+    assert _lib.check_small_kernel_lds_reads() > 50
+    good = """
+0000000000001000 <_ZN3pcc17conv_small_kernelILi1ELi8EEEvNS_8ConvArgsE>:
+	ds_read_b128 v[14:17], v8                                  // 000000032A64: D9FE0000
+	v_mfma_f32_16x16x4_f32 v[0:3], v40, v41, v[0:3]            // 000000032A6C: D3C50000
+	s_waitcnt lgkmcnt(0)                                       // 000000032B64: BF8CC07F
+	v_cndmask_b32_e64 v40, v14, v15, s[4:5]                    // 000000032B68: D1000028
+	s_endpgm
+"""
+    assert _lib.lint_lds_reads(good) == 1
+    bad = good.replace("v_mfma_f32_16x16x4_f32 v[0:3], v40, v41, v[0:3]", "v_mov_b32_e32 v90, v15")
+    import pytest
+    with pytest.raises(RuntimeError, match="still in flight"):
+        _lib.lint_lds_reads(bad)
