@@ -167,10 +167,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="config2", choices=["config1", "config2", "mid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-order", default="kernel", choices=["kernel", "blas"],
+                    help="summation order of the CPU baseline's oracle: kernel = hand-vectorised fused multiply-add chains (the faster CPU "
+                         "implementation, ~45 s on the config-2 frame; the HIP path must reproduce its bytes), blas = torch-CPU sgemm (~130 s)")
     ap.add_argument("--cpu-sample", default="1024,260,0.5",
                     help="grid,radius,half_width of the CPU-baseline shell.  Default: the config-2 frame itself (N = 850,824: "
-                         "~2.5 minutes on 16 host cores), so cpu_baseline and cpu_baseline.parity are on the headline workload; "
-                         "256,100,0.5 is a bounded 125,672-point sample (~20 s)")
+                         "~45 s on 16 host cores in kernel order, ~2.5 minutes in BLAS order), so cpu_baseline and cpu_baseline.parity are "
+                         "on the headline workload; 256,100,0.5 is a bounded 125,672-point sample")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--partition", default="frames", choices=["frames", "blocks"],
                     help="N > 1 sharding: one frame per rank (weak scaling, the default) or the cubes of ONE frame "
@@ -200,13 +203,18 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(model, state_dict, sample, dev):
+def cpu_baseline(model, state_dict, sample, dev, order="kernel"):
     """The oracle (CPU restatement, kind 'port') timed on a bounded sample of the same workload; the HIP codec then
     codes the SAME frame with the same weights and both results go into ``parity`` (the oracle run is the checker
-    here, never the thing measured as ``value``)."""
+    here, never the thing measured as ``value``).  ``order``: the oracle's summation order (oracle/nn.py) — "kernel" (default:
+    every convolution as one fused multiply-add chain, hand-vectorised C on all host cores: the FASTER of the two CPU
+    implementations, hence the baseline, and the one whose bytes the HIP path must reproduce) or "blas" (torch-CPU gather ->
+    sgemm -> index_add_, three times slower; the independent restatement, compared within BASELINE's tolerances)."""
+    from oracle import nn as oracle_nn
     from oracle.codec import Codec, count_bits
     from oracle.metrics import pc_metrics
     import pcc_amd
+    was_order = oracle_nn.set_order(order)
     grid, radius, hw = sample.split(",")
     pts = pcc_amd.synthetic.sphere_shell(int(grid), float(radius), float(hw))
     qc, qf = pcc_amd.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
@@ -245,9 +253,16 @@ def cpu_baseline(model, state_dict, sample, dev):
     parity["abs_diff"] = {"bpp": abs(parity["bpp"]["hip"] - parity["bpp"]["oracle"]),
                           "d1_psnr_db": abs(parity["d1_psnr_db"]["hip"] - parity["d1_psnr_db"]["oracle"]),
                           "y_psnr_db": abs(parity["y_psnr_db"]["hip"] - parity["y_psnr_db"]["oracle"])}
+    parity["oracle_summation_order"] = order
+    parity["streams_byte_equal"] = bool(h_strings[0][0] == strings[0][0] and h_strings[1][0] == strings[1][0])
+    if flips == 0:
+        key = lambda r_: r_[np.lexsort((r_[:, 2], r_[:, 1], r_[:, 0]))]
+        parity["colours_differing"] = int((np.rint(key(h_rec)[:, 3:6] * 255.0) != np.rint(key(o_rec)[:, 3:6] * 255.0)).sum())
+    oracle_nn.set_order(was_order)
+    how = ("oracle/chain.c fused multiply-add chains on all cores + C rANS" if order == "kernel" else "torch-CPU sgemm + C rANS oracle")
     return {"value": n / (t2 - t0) / 1e6, "unit": "Mpoints/s", "cores": threads, "cpu_model": cpu_model_name(), "kind": "port",
             "sample": f"one {grid}^3 sphere-shell frame, N={n} points, q=(0.5,0.5), same weights; "
-                      f"t_enc={t1 - t0:.2f}s t_dec={t2 - t1:.2f}s (torch-CPU sgemm + C rANS oracle)",
+                      f"t_enc={t1 - t0:.2f}s t_dec={t2 - t1:.2f}s ({how})",
             "parity": parity}
 
 
@@ -1028,7 +1043,7 @@ def main():
         out["file_mode"] = file_mode
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {n_: t.detach().cpu() for n_, t in model.state_dict().items()}
-        out["cpu_baseline"] = cpu_baseline(model, sd, args.cpu_sample, dev)
+        out["cpu_baseline"] = cpu_baseline(model, sd, args.cpu_sample, dev, args.cpu_order)
     elif rank == 0:
         # N > 1 (and --no-cpu-baseline): the baseline is measured on rank 0 at N = 1 only (minutes of host work); carry the newest
         # committed N = 1 record along, labelled as replayed, so that a scaling line is as complete as the N = 1 line

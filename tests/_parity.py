@@ -135,8 +135,18 @@ def assert_exact(oracle_codec, pts, qc, qf, strings, shape, k, coords, rec, tag=
         on.set_order(was)
 
 
-def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0", strict=False, exact=True):
-    """HIP codec vs CPU oracle on one frame (module docstring).  Returns a dict of what was measured."""
+class _Rows:
+    """(C, F) of an oracle tensor that was computed elsewhere (tests/_config2_blas_worker.py)"""
+
+    def __init__(self, C, F):
+        import torch
+        self.C, self.F = C, torch.from_numpy(np.ascontiguousarray(F))
+
+
+def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0", strict=False, exact=True, oracle_results=None):
+    """HIP codec vs CPU oracle on one frame (module docstring).  Returns a dict of what was measured.
+    ``oracle_results``: the BLAS-order oracle's outputs for this very frame computed by a background process (a dict of arrays:
+    tests/_config2_blas_worker.py) instead of calling ``oracle_codec`` here."""
     import torch
     from oracle import nn as on
     from oracle.codec import count_bits
@@ -146,7 +156,12 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0",
     x = torch.from_numpy(pts).to(dev)
     Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(dev), features=torch.from_numpy(qf).to(dev), device=dev)
     strings, shape, k, coords = model.compress(x, Q)
-    o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
+    if oracle_results is None:
+        o_strings, o_shape, o_k, o_coords = oracle_codec.compress(pts, qc, qf)
+    else:
+        R = oracle_results
+        o_strings = [[R["y_stream"].tobytes()], [R["z_stream"].tobytes()]]
+        o_shape, o_k, o_coords = [int(v) for v in R["shape"]], [[int(v) for v in row] for row in R["k"]], R["coords"]
     # exact: structure
     assert shape == o_shape and k == o_k, tag
     got_c = coords.cpu().numpy()
@@ -159,8 +174,12 @@ def compare_codec(pcc, model, oracle_codec, pts, qc, qf, tag=None, dev="cuda:0",
     with torch.no_grad():
         y_hat, Q_hat = model.entropy_model.decompress([c8, c8.down().down()], strings, shape)
     rec = model.reconstruct(y_hat, Q_hat, k).cpu().numpy()
-    o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
-    o_y, o_Q = oracle_codec.last_dec["y_hat"], oracle_codec.last_dec["Q_hat"]
+    if oracle_results is None:
+        o_rec = oracle_codec.decompress(o_coords, o_strings, o_shape, o_k)
+        o_y, o_Q = oracle_codec.last_dec["y_hat"], oracle_codec.last_dec["Q_hat"]
+    else:
+        o_rec = oracle_results["rec"]
+        o_y, o_Q = _Rows(oracle_results["y_C"], oracle_results["y_F"]), _Rows(oracle_results["Q_C"], oracle_results["Q_F"])
     assert rec.shape == o_rec.shape == (N, 6), tag
     # stage 1, the encoders' discrete decisions: decoded latents equal except for whole quantisation steps (counted)
     assert np.array_equal(y_hat.C.cpu().numpy(), o_y.C), tag                   # both in canonical (bitstream) order
