@@ -159,7 +159,7 @@ int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_
  *   v = act(v)                                            (MinkowskiReLU / LeakyReLU)
  *   if residual: v += residual[j, c]                      (blocks.py:49-52)
  * W is the ME kernel tensor [K, cin, cout] (fp32).  For cin % 32 == 0 the MFMA path is used
- * and needs `w_packed` from pcc_conv_pack_weights; otherwise (cin in {1,2,4,8,16}) the
+ * and needs `w_packed` from pcc_conv_pack_weights; otherwise (cin in {1,2,3,4,6,8,12,16,24}) the
  * thin path reads `w` directly.  nbr == NULL means kernel_size 1 (identity map, K = 1).
  * MFMA path: if `order` != NULL, position p computes output row order[p] and `group_mask32` holds the
  * masks from pcc_order_rows_by_mask; with order == NULL rows run in natural order (group_mask32 may

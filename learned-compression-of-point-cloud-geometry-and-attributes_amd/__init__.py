@@ -24,7 +24,7 @@ from .sparse import (CoordMap, SparseTensor, MinkowskiConvolution, MinkowskiConv
 from .entropy import EntropyBottleneck, GaussianConditional  # noqa: F401
 from .blocks import ScaledBlock, GenerativeUpBlock, ConditionEncoder  # noqa: F401
 from .transforms import AnalysisTransform, SparseSynthesisTransform  # noqa: F401
-from .entropy_models import MeanScaleHyperprior_Map  # noqa: F401
+from .entropy_models import MeanScaleHyperprior, MeanScaleHyperprior_Map  # noqa: F401
 from .model import ColorModel  # noqa: F401
 from . import synthetic, utils, parallel  # noqa: F401
 

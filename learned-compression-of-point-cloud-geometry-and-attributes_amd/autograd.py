@@ -18,7 +18,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr
 
-_THIN_CIN = (1, 2, 4, 8, 16)
+_THIN_CIN = (1, 2, 3, 4, 6, 8, 12, 16, 24)
 
 # bf16 compute for the training path (BASELINE config 5: "bf16"): convolutions whose input width is a multiple of
 # 64 cast their input (forward: the features; backward-data: the output gradient) and weights to bf16 and run on
@@ -214,7 +214,7 @@ class SparseConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = w.transpose(1, 2)                                  # [K, cout, cin]
             g = g_w if (ctx.needs_input_grad[1] and feats.dtype == torch.bfloat16 and cout % 64 == 0 and _bf16_ok(n_out, cout)) else dy
-            if cout % 32 and cout not in _THIN_CIN:                 # the thin forward kernel takes 1, 2, 4, 8 or 16 input channels
+            if cout % 32 and cout not in _THIN_CIN:                 # input widths of the thin forward kernel: _THIN_CIN
                 pad = next(c for c in _THIN_CIN if c >= cout) - cout
                 g = torch.cat([dy, torch.zeros((n_out, pad), dtype=torch.float32, device=dev)], dim=1).contiguous()
                 wt = torch.cat([wt, torch.zeros((K, pad, cin), dtype=torch.float32, device=dev)], dim=1)

@@ -1515,11 +1515,15 @@ int pcc_conv_fwd(const float* fin, int64_t n_in, int32_t cin, const float* w, co
     switch (cin) {
         case 1: return launch_thin<1>(a, st);
         case 2: return launch_thin<2>(a, st);
-        case 4: return launch_thin<4>(a, st);
+        case 3: return launch_thin<3>(a, st);        // 3, 6, 12, 24: C_bottleneck * 3 / 2 of a hyperprior over a narrow tensor
+        case 4: return launch_thin<4>(a, st);        // (the two-hyperprior variant codes the 2-channel q-map: model/entropy_models.py:140-147)
+        case 6: return launch_thin<6>(a, st);
         case 8: return launch_thin<8>(a, st);
+        case 12: return launch_thin<12>(a, st);
         case 16: return launch_thin<16>(a, st);
+        case 24: return launch_thin<24>(a, st);
         default:
-            pcc::set_error("pcc_conv_fwd: unsupported cin=%d (need a multiple of 32 or one of 1,2,4,8,16)", cin);
+            pcc::set_error("pcc_conv_fwd: unsupported cin=%d (need a multiple of 32 or one of 1,2,3,4,6,8,12,16,24)", cin);
             return PCC_ERR_UNSUPPORTED;
     }
 }

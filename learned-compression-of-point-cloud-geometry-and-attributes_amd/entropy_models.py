@@ -1,7 +1,9 @@
-"""Mean-scale hyperprior on sparse tensors with the q-map decoded from z_hat.
+"""Mean-scale hyperpriors on sparse tensors.
 
-Mirror of ``MeanScaleHyperprior_Map`` (/root/reference/model/entropy_models.py:253-414): h_a, h_s,
-h_q, factorized bottleneck on z, Gaussian conditional on y, one rANS stream each.
+Mirror of ``MeanScaleHyperprior_Map`` (/root/reference/model/entropy_models.py:253-414: h_a, h_s,
+h_q — the q-map decoded from z_hat —, factorized bottleneck on z, Gaussian conditional on y, one rANS
+stream each; every shipped config) and of ``MeanScaleHyperprior`` (:104-250: the same without h_q;
+model/model.py:22-24 instantiates it twice when the config has an "entropy_model_map" section).
 
 Differences in *how* (never in *what*):
 * the reference's ``Sorted*`` shims (entropy_models.py:12-102) exist to make h_s reproducible
@@ -24,6 +26,96 @@ from .sparse import (ConvChain, CoordMap, MinkowskiConvolution, MinkowskiConvolu
 
 def _c(cin, cout, k=3, s=1, bias=False):
     return MinkowskiConvolution(in_channels=cin, out_channels=cout, kernel_size=k, stride=s, bias=bias, dimension=3)
+
+
+class MeanScaleHyperprior(nn.Module):
+    """``MeanScaleHyperprior`` (/root/reference/model/entropy_models.py:104-250): h_a, factorized z, h_s, Gaussian y — the entropy model
+    of the two-hyperprior variant of ColorModel (model/model.py:22-24: one instance codes y, a second the stride-8 q-map).  The layers
+    of MeanScaleHyperprior_Map without h_q; same parameter names as the reference, same remarks as in the module docstring."""
+
+    def __init__(self, config):
+        super().__init__()
+        Cb, Ch = config["C_bottleneck"], config["C_hyper_bottleneck"]
+        self.C_bottleneck = Cb
+        self.entropy_bottleneck = EntropyBottleneck(Ch)
+        self.gaussian_conditional = GaussianConditional(None)
+        self.h_a = ConvChain(
+            _c(Cb, Ch), MinkowskiLeakyReLU(),
+            _c(Ch, Ch, 3, 2), _c(Ch, Ch), MinkowskiLeakyReLU(),
+            _c(Ch, Ch, 3, 2), _c(Ch, Ch))
+        gT = lambda cin, cout, k: MinkowskiGenerativeConvolutionTranspose(
+            in_channels=cin, out_channels=cout, kernel_size=k, stride=2, bias=True, dimension=3)
+        self.h_s = ConvChain(
+            _c(Ch, Ch, bias=True), gT(Ch, Ch, 2), MinkowskiLeakyReLU(),
+            _c(Ch, Ch, bias=True), gT(Ch, Cb * 3 // 2, 2), MinkowskiLeakyReLU(),
+            _c(Cb * 3 // 2, Cb * 2, bias=True))
+
+    def update(self, scale_table=None, force=False):
+        """CompressionModel.update: EB tables + the 64-level Gaussian table (model/model.py:30-36)"""
+        if scale_table is None:
+            scale_table = get_scale_table()
+        updated = self.gaussian_conditional.update_scale_table(scale_table, force=force)
+        updated |= self.entropy_bottleneck.update(force=force)
+        return updated
+
+    def aux_loss(self):
+        return self.entropy_bottleneck.loss()
+
+    def _params_at(self, z_hat, y_map):
+        return self.h_s(z_hat, last_out_map=y_map).F
+
+    def forward(self, y):
+        """entropy_models.py:145-169 -> y_hat, (L_y, L_z)"""
+        z = self.h_a(y)
+        if self.training:
+            from . import entropy as _e
+            _e.NOISE_ROWS = z.C
+            z_hat_f, z_lik = self.entropy_bottleneck(z.F.t().unsqueeze(0))
+            z_hat = SparseTensor(z_hat_f[0].t().contiguous(), coordinate_map=z.map)
+            scales, means = self._params_at(z_hat, y.map).chunk(2, dim=1)
+            _e.NOISE_ROWS = y.C
+            y_hat_f, y_lik = self.gaussian_conditional(y.F.t().unsqueeze(0), scales.t().unsqueeze(0), means=means.t().unsqueeze(0))
+            return SparseTensor(y_hat_f[0].t().contiguous(), coordinate_map=y.map), (y_lik, z_lik)
+        z_hat_f, z_lik = self.entropy_bottleneck(z.F.t().unsqueeze(0))
+        z_hat = SparseTensor(z_hat_f[0].t().contiguous(), coordinate_map=z.map)
+        y_hat_f, y_lik = self.gaussian_conditional.forward_features(y.F, self._params_at(z_hat, y.map))
+        return SparseTensor(y_hat_f, coordinate_map=y.map), (y_lik.unsqueeze(0), z_lik)
+
+    def compress(self, y):
+        """entropy_models.py:172-212 -> (points, strings, shape)"""
+        z = self.h_a(y)
+        perm_y = y.map.sort_permutation()
+        perm_z = z.map.sort_permutation()
+        shape = [z.map.n]
+        finish_z, z_hat_f = self.entropy_bottleneck.compress_features_begin(z.F, perm=perm_z)
+        z_hat = SparseTensor(z_hat_f, coordinate_map=z.map)
+        finish_y = self.gaussian_conditional.compress_features_begin(y.F, self._params_at(z_hat, y.map), perm=perm_y)
+        z_strings = finish_z()
+        y_strings = finish_y()
+        points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
+        return points, [y_strings, z_strings], shape
+
+    def decompress(self, points, strings, shape):
+        """entropy_models.py:215-250 -> y_hat on the canonically sorted stride-8 coordinates; ``points`` = [coords8, coords32]
+        or CoordMaps (already canonically sorted ones are taken as they are: the two models of a codec share them)"""
+        assert isinstance(strings, list) and len(strings) == 2
+        y_sorted, z_sorted = (_canonical_map(m, s) for m, s in zip(points, (8, 32)))
+        y_strings, z_strings = strings
+        finish_z = self.entropy_bottleneck.decompress_features_async(z_strings, int(shape[0]), z_sorted.device)
+        z_hat = SparseTensor(finish_z(), coordinate_map=z_sorted)
+        finish_y = self.gaussian_conditional.decompress_features_async(y_strings, self._params_at(z_hat, y_sorted), self.C_bottleneck)
+        return SparseTensor(finish_y(), coordinate_map=y_sorted)
+
+
+def _canonical_map(m, stride):
+    """coordinates or a CoordMap -> the CoordMap of the same set in canonical (b, x, y, z) order = bitstream order (utils.sort_points)"""
+    if not isinstance(m, CoordMap):
+        m = CoordMap(sp._as_int_coords(m), stride)
+    if getattr(m, "_canonical", False):
+        return m
+    out = CoordMap(m.coords.index_select(0, m.sort_permutation().long()), stride, nbatch=m._nbatch)
+    out._canonical = True
+    return out
 
 
 class MeanScaleHyperprior_Map(nn.Module):

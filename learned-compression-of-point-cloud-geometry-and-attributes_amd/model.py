@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from . import octree
 from . import sparse as sp
-from .entropy_models import MeanScaleHyperprior_Map
+from .entropy_models import MeanScaleHyperprior, MeanScaleHyperprior_Map, _canonical_map
 from .sparse import CoordMap, SparseTensor
 from .transforms import AnalysisTransform, SparseSynthesisTransform
 
@@ -29,17 +29,24 @@ class ColorModel(nn.Module):
         self.g_a = AnalysisTransform(config["g_a"])
         self.g_s = SparseSynthesisTransform(config["g_s"])
         if "entropy_model_map" in config:
-            raise NotImplementedError("the two-hyperprior variant (model/model.py:22-24) is not used by any "
-                                      "shipped config and is outside this path")
-        self.entropy_model = MeanScaleHyperprior_Map(config["entropy_model"])
-        self.entropy_model_map = None
+            # model/model.py:22-24: one hyperprior for y, a second one codes the stride-8 q-map (no shipped config selects it)
+            self.entropy_model = MeanScaleHyperprior(config["entropy_model"])
+            self.entropy_model_map = MeanScaleHyperprior(config["entropy_model_map"])
+        else:
+            self.entropy_model = MeanScaleHyperprior_Map(config["entropy_model"])
+            self.entropy_model_map = None
 
     # -- model/model.py:30-47 ------------------------------------------------------------------
     def update(self, force=True):
-        return self.entropy_model.update(force=force)
+        updated = self.entropy_model.update(force=force)
+        if self.entropy_model_map is not None:
+            updated |= self.entropy_model_map.update(force=force)
+        return updated
 
     def aux_loss(self):
-        return self.entropy_model.aux_loss()
+        if self.entropy_model_map is None:
+            return self.entropy_model.aux_loss()
+        return self.entropy_model.aux_loss() + self.entropy_model_map.aux_loss()
 
     @property
     def device(self):
@@ -51,8 +58,13 @@ class ColorModel(nn.Module):
         ones = torch.ones((x.map.n, 1), dtype=torch.float32, device=x.device)
         x = SparseTensor(torch.cat([ones, x.F], dim=1), coordinate_map=x.map)
         y, Q, k = self.g_a(x, Q)
-        y_hat, Q_hat, likelihoods = self.entropy_model(y)
-        likelihoods = {"y": likelihoods[0], "z": likelihoods[1]}
+        if self.entropy_model_map is None:
+            y_hat, Q_hat, likelihoods = self.entropy_model(y)
+            likelihoods = {"y": likelihoods[0], "z": likelihoods[1]}
+        else:
+            y_hat, y_likelihoods = self.entropy_model(y)
+            Q_hat, Q_likelihoods = self.entropy_model_map(Q)
+            likelihoods = {"y": [y_likelihoods[0], Q_likelihoods[0]], "z": [y_likelihoods[1], Q_likelihoods[1]]}
         x_hat, points, predictions = self.g_s(y_hat, Q_hat, coords=coords, k=k)
         return {"prediction": x_hat, "points": points, "occ_predictions": predictions, "q_map": Lambda,
                 "likelihoods": likelihoods}
@@ -81,8 +93,16 @@ class ColorModel(nn.Module):
         inp = SparseTensor(feats, coordinate_map=CoordMap(coords.contiguous(), 1, nbatch=nbatch))
         if Q.map._nbatch is None:
             Q.map._nbatch = nbatch
-        y, _, k = self.g_a(inp, Q)
-        points, strings, shape = self.entropy_model.compress(y)
+        y, Q8, k = self.g_a(inp, Q)
+        if self.entropy_model_map is None:
+            points, strings, shape = self.entropy_model.compress(y)
+        else:
+            if path:
+                raise ValueError("file mode: the container's header has fields for ONE (y, z) stream pair (model/model.py:243-250); "
+                                 "the two-hyperprior variant returns two pairs — use the in-memory API")
+            points, y_strings, y_shape = self.entropy_model.compress(y)
+            _, Q_strings, Q_shape = self.entropy_model_map.compress(Q8)
+            strings, shape = [y_strings, Q_strings], [y_shape, Q_shape]
         coordinates = y.C
         if path:
             self.save_bitstream(path=path, points=coordinates, strings=strings, shape=shape, k=k)
@@ -95,6 +115,8 @@ class ColorModel(nn.Module):
         """``return_batch`` (not in the reference's signature): also return the item index of every decoded
         point — for streams produced by ``compress(..., batch=...)``."""
         device = self.device
+        if path and self.entropy_model_map is not None:
+            raise ValueError("file mode holds one (y, z) stream pair; the two-hyperprior variant needs two (see compress)")
         if path:
             coordinates, strings, shape, k = self.load_bitstream(path)
             coordinates = coordinates.to(device)
@@ -103,7 +125,12 @@ class ColorModel(nn.Module):
         nbatch = len(k[0]) if isinstance(k[0], (list, tuple)) else 1          # one count per item and stage
         c8 = CoordMap(sp._as_int_coords(coordinates.to(device)), 8, nbatch=nbatch)
         c32 = c8.down().down()      # coordinates only (g_s.down_conv applied twice, model.py:188-190)
-        y_hat, Q_hat = self.entropy_model.decompress([c8, c32], strings, shape)
+        if self.entropy_model_map is None:
+            y_hat, Q_hat = self.entropy_model.decompress([c8, c32], strings, shape)
+        else:
+            points = [_canonical_map(c8, 8), _canonical_map(c32, 32)]          # model/model.py:197-201: both models decode on the same lists
+            y_hat = self.entropy_model.decompress(points, strings[0], shape[0])
+            Q_hat = self.entropy_model_map.decompress(points, strings[1], shape[1])
         return self.reconstruct(y_hat, Q_hat, k, return_batch)
 
     @torch.no_grad()

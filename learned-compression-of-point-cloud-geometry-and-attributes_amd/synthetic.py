@@ -29,6 +29,15 @@ ABLATION_NOCONDITION_CONFIG = {
     "g_s": {"C_out": 3, "N1": 128, "N2": 128, "N3": 64, "source_condition": False, "condition_ablation": "condition_ablation"},
 }
 
+# the two-hyperprior variant model/model.py:22-24 selects when the config has an "entropy_model_map" section (no shipped yaml has one;
+# the widths of the q-map's model are this build's choice: 2 channels in, 8 in the hyper bottleneck -> h_s widths 8, 8, 3, 4)
+TWO_HYPERPRIOR_CONFIG = {
+    "entropy_model": {"type": "MeanScaleHyperprior", "C_bottleneck": 128, "C_hyper_bottleneck": 128},
+    "entropy_model_map": {"type": "MeanScaleHyperprior", "C_bottleneck": 2, "C_hyper_bottleneck": 8},
+    "g_a": {"C_in": 4, "N1": 64, "N2": 128, "N3": 128, "source_condition": True},
+    "g_s": {"C_out": 3, "N1": 128, "N2": 128, "N3": 64, "source_condition": True},
+}
+
 CONFIG1 = dict(grid=32, radius=15.0, half_width=0.875)       # N = 4,904
 CONFIG2 = dict(grid=1024, radius=260.0, half_width=0.5)      # N = 850,824
 
@@ -138,6 +147,18 @@ def seeded_init(model, seed=0, film_gain=FILM_GAIN_DEFAULT):
     for i in range(5):
         b = getattr(eb, f"_bias{i}")
         b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(b.device))
+    emq = getattr(model, "entropy_model_map", None)
+    if emq is not None:
+        # the second hyperprior codes the stride-8 q-map ROUNDED TO INTEGERS (model/model.py:77): spread it over several bins
+        model.g_a.condition_encoder.down_layers[2].kernel.mul_(3.0)
+        last = emq.h_s[6]
+        C = emq.C_bottleneck
+        last.kernel[:, :, :C].mul_(0.15)
+        last.bias[:, :C].add_(0.8)
+        last.kernel[:, :, C:].mul_(0.1)
+        for i in range(5):
+            b = getattr(emq.entropy_bottleneck, f"_bias{i}")
+            b.copy_((torch.rand(b.shape, generator=g) - 0.5).to(b.device))
     return model
 
 

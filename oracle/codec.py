@@ -2,7 +2,7 @@
 
 CPU restatement of /root/reference/model/model.py:51-208 (+ container :214-315),
 model/transforms.py:8-304, model/blocks.py:10-53,78-251 and
-model/entropy_models.py:253-414 for ``configs/Ours.yaml`` style configs,
+model/entropy_models.py:253-414 (and :104-250, the two-hyperprior variant) for ``configs/Ours.yaml`` style configs,
 driven by a flat ``state_dict`` whose keys follow the reference module tree
 (SURVEY.md Appendix A).  Test infrastructure only — see oracle/__init__.py.
 """
@@ -193,29 +193,84 @@ def h_q(p, z):
     return p.conv(h, "6")
 
 
+class Hyperprior:
+    """``MeanScaleHyperprior`` (entropy_models.py:104-250): h_a, factorized z, h_s, Gaussian y — the entropy model the
+    two-hyperprior variant of ColorModel (model/model.py:22-24) instantiates twice, for y and for the stride-8 q-map.
+    The same layers as MeanScaleHyperprior_Map minus h_q."""
+
+    def __init__(self, p, gc):
+        self.p = p
+        self.eb = EntropyBottleneck(p.sub("entropy_bottleneck"))
+        self.gc = gc
+
+    def _gaussian_params(self, z_hat, y_coords):
+        gp = h_s(self.p.sub("h_s"), z_hat).features_at_coordinates(y_coords)
+        scales, means = gp.chunk(2, dim=1)
+        return scales.t().unsqueeze(0).contiguous(), means.t().unsqueeze(0).contiguous()
+
+    def compress(self, y):
+        """entropy_models.py:172-212 -> (strings [y, z], shape, intermediates)"""
+        z = h_a(self.p.sub("h_a"), y)
+        y, z = y.sorted(), z.sorted()
+        shape = [z.F.shape[0]]
+        z_strings = self.eb.compress(z.F.t().unsqueeze(0))
+        z_hat = SparseTensor(z.C, self.eb.decompress(z_strings, shape[0])[0].t().contiguous(), 32)
+        scales, means = self._gaussian_params(z_hat, y.C)
+        indexes = self.gc.build_indexes(scales)
+        y_strings = self.gc.compress(y.F.t().unsqueeze(0).contiguous(), indexes, means)
+        return [y_strings, z_strings], shape, dict(y=y, z=z, z_hat=z_hat, scales=scales, means=means, indexes=indexes)
+
+    def decompress(self, y_pts, z_pts, strings, shape):
+        """entropy_models.py:215-250 -> y_hat on the canonically sorted stride-8 coordinates"""
+        z_hat = SparseTensor(z_pts, self.eb.decompress(strings[1], shape[0])[0].t().contiguous(), 32)
+        scales, means = self._gaussian_params(z_hat, y_pts)
+        y_hat = self.gc.decompress(strings[0], self.gc.build_indexes(scales), means)
+        return SparseTensor(y_pts, y_hat[0].t().contiguous(), 8)
+
+    def forward_eval(self, y):
+        """entropy_models.py:145-169 in eval mode -> y_hat, (L_y, L_z), z's coordinates"""
+        z = h_a(self.p.sub("h_a"), y)
+        z_hat_f, z_lik = self.eb.forward_eval(z.F.t().unsqueeze(0))
+        z_hat = SparseTensor(z.C, z_hat_f[0].t().contiguous(), 32)
+        scales, means = self._gaussian_params(z_hat, y.C)
+        y_hat_f, y_lik = self.gc.forward_eval(y.F.t().unsqueeze(0), scales, means)
+        return SparseTensor(y.C, y_hat_f[0].t().contiguous(), 8), (y_lik, z_lik), z.C
+
+
 class Codec:
     """Functional restatement of ``ColorModel`` (model/model.py:15-208)."""
 
-    def __init__(self, state_dict, config=None):
+    def __init__(self, state_dict, config=None, leaves=False):
         """``config``: the model section of the yaml ({"g_a": {...}, "g_s": {...}, ...}); None = configs/Ours.yaml.  Only the
-        switches that change the forward pass are read: source_condition, condition_ablation (g_a), dense (g_s)."""
+        switches that change the forward pass are read: source_condition, condition_ablation (g_a), dense (g_s), and the presence
+        of an "entropy_model_map" section.  ``leaves``: use the tensors of ``state_dict`` as they are (autograd leaves of
+        oracle/train.py) instead of detached copies."""
         self.cfg_a = dict((config or {}).get("g_a", {}))
         self.cfg_s = dict((config or {}).get("g_s", {}))
-        self.sd = {k: torch.as_tensor(v).detach().to(torch.float32).cpu() for k, v in state_dict.items()
-                   if torch.as_tensor(v).dtype.is_floating_point}
+        self.sd = state_dict if leaves else {k: torch.as_tensor(v).detach().to(torch.float32).cpu() for k, v in state_dict.items()
+                                             if torch.as_tensor(v).dtype.is_floating_point}
         self.p = Params(self.sd)
         self.eb = EntropyBottleneck(self.p.sub("entropy_model").sub("entropy_bottleneck"))
         self.gc = GaussianConditional()
+        # model/model.py:22-27: an "entropy_model_map" section selects two MeanScaleHyperprior models (y and the stride-8 q-map)
+        self.two = "entropy_model_map" in (config or {})
+        if self.two:
+            self.em_y = Hyperprior(self.p.sub("entropy_model"), self.gc)
+            self.em_y.eb = self.eb
+            self.em_q = Hyperprior(self.p.sub("entropy_model_map"), self.gc)
         self.updated = False
 
     def update(self):
         """model/model.py:30-36."""
         self.eb.update()
+        if self.two:
+            self.em_q.eb.update()
         self.gc.update()
         self.updated = True
 
     def aux_loss(self):
-        return self.eb.aux_loss()
+        """model/model.py:40-47"""
+        return self.eb.aux_loss() + (self.em_q.eb.aux_loss() if self.two else 0.0)
 
     # -- model.py:95-147 -------------------------------------------------------------
     def compress(self, x, Q_coords, Q_feats, batch=None):
@@ -234,7 +289,12 @@ class Codec:
         feats = torch.from_numpy(np.concatenate([np.ones((N, 1), np.float32), x[:, 3:6]], axis=1))
         inp = SparseTensor(pts, feats, 1)
         Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
-        y, _, k = analysis(self.p.sub("g_a"), inp, Q, self.cfg_a)
+        y, Q8, k = analysis(self.p.sub("g_a"), inp, Q, self.cfg_a)
+        if self.two:
+            # model/model.py:132-136: strings = [[y, z] of the latents, [y, z] of the q-map], shape likewise
+            y_strings, y_shape, self.last = self.em_y.compress(y)
+            q_strings, q_shape, self.last_q = self.em_q.compress(Q8)
+            return [y_strings, q_strings], [y_shape, q_shape], k, y.C.copy()
         em = self.p.sub("entropy_model")
         z = h_a(em.sub("h_a"), y)
         y = y.sorted()
@@ -261,6 +321,15 @@ class Codec:
         c32 = oc.stride_map(c16, 16)
         y_pts = c8[oc.sort_order(c8)]
         z_pts = c32[oc.sort_order(c32)]
+        if self.two:
+            # model/model.py:197-201: both models decode on the same [stride-8, stride-32] point lists
+            y_hat = self.em_y.decompress(y_pts, z_pts, strings[0], shape[0])
+            Q_hat = self.em_q.decompress(y_pts, z_pts, strings[1], shape[1])
+            x_hat = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k, cfg=self.cfg_s)
+            feats = torch.clamp(torch.round(x_hat.F * 255), 0.0, 255.0) / 255
+            self.last_dec = dict(y_hat=y_hat, Q_hat=Q_hat, x_hat=x_hat)
+            self.last_batch = x_hat.C[:, 0].copy()
+            return np.concatenate([x_hat.C[:, 1:4].astype(np.float32), feats.numpy()], axis=1)
         em = self.p.sub("entropy_model")
         z_hat = self.eb.decompress(strings[1], shape[0])
         z_hat = SparseTensor(z_pts, z_hat[0].t().contiguous(), 32)
@@ -286,7 +355,15 @@ class Codec:
         feats = torch.cat([torch.ones((N, 1)), torch.as_tensor(colors, dtype=torch.float32)], dim=1)
         x = SparseTensor(coords, feats, 1)
         Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
-        y, _, k = analysis(self.p.sub("g_a"), x, Q, self.cfg_a)
+        y, Q8, k = analysis(self.p.sub("g_a"), x, Q, self.cfg_a)
+        if self.two:
+            # model/model.py:75-78: likelihoods = {"y": [L_y, L_Q], "z": [L_zy, L_zQ]}
+            y_hat, (y_lik, zy_lik), z_rows = self.em_y.forward_eval(y)
+            Q_hat, (q_lik, zq_lik), zq_rows = self.em_q.forward_eval(Q8)
+            x_hat, points, preds = synthesis(self.p.sub("g_s"), y_hat, Q_hat, k, coords=coords, cfg=self.cfg_s)
+            return {"prediction": x_hat, "points": points, "occ_predictions": preds,
+                    "likelihoods": {"y": [y_lik, q_lik], "z": [zy_lik, zq_lik]}, "k": k,
+                    "rows": {"y": y.C, "z": z_rows, "q": Q8.C, "zq": zq_rows}, "y_hat": y_hat, "Q_hat": Q_hat}
         em = self.p.sub("entropy_model")
         z = h_a(em.sub("h_a"), y)
         z_hat_f, z_lik = self.eb.forward_eval(z.F.t().unsqueeze(0))

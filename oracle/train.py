@@ -38,35 +38,47 @@ def leaf_state_dict(state_dict):
             for k, v in state_dict.items() if torch.as_tensor(v).dtype.is_floating_point}
 
 
-def forward_train(codec, coords, colors, Q_coords, Q_feats, noise):
-    """codec: oracle.codec.Codec built on leaf_state_dict(...); noise(shape, coords) -> tensor, called for z
-    ([C, 1, N32]) then y ([1, C, N8]) with the points' coordinates (row order is implementation-specific)"""
-    coords = oc.to_int_coords(coords)
-    N = coords.shape[0]
-    feats = torch.cat([torch.ones((N, 1)), torch.as_tensor(colors, dtype=torch.float32)], dim=1)
-    x = SparseTensor(coords, feats, 1)
-    Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
-    y, _, k = analysis(codec.p.sub("g_a"), x, Q, getattr(codec, "cfg_a", None))
-    em = codec.p.sub("entropy_model")
-    z = h_a(em.sub("h_a"), y)
+def _hyper_train(eb, gc, p, y, noise, with_q=False):
+    """one hyperprior in training mode (entropy_models.py:145-169 / :309-337): h_a, noisy z and its likelihood, h_s, noisy y and its
+    likelihood -> y_hat, y_lik, z_lik, (Q_hat from h_q when ``with_q``)"""
+    z = h_a(p.sub("h_a"), y)
     v = z.F.t().unsqueeze(0).permute(1, 0, 2)                        # [C, 1, N]
     v = v + noise(tuple(v.shape), z.C)
-    z_lik, _, _ = codec.eb._likelihood_raw(v)
+    z_lik, _, _ = eb._likelihood_raw(v)
     z_lik = _LowerBound.apply(z_lik, LIKELIHOOD_BOUND).permute(1, 0, 2)
     z_hat = SparseTensor(z.C, v.permute(1, 0, 2)[0].t().contiguous(), 32)
-    params = h_s(em.sub("h_s"), z_hat)
-    Q_hat = h_q(em.sub("h_q"), z_hat)
+    params = h_s(p.sub("h_s"), z_hat)
+    Q_hat = h_q(p.sub("h_q"), z_hat) if with_q else None
     scales, means = params.features_at_coordinates(y.C).chunk(2, dim=1)
     scales, means = scales.t().unsqueeze(0), means.t().unsqueeze(0)
     yin = y.F.t().unsqueeze(0)
     yout = yin + noise(tuple(yin.shape), y.C)
     a = torch.abs(yout - means)
     s = _LowerBound.apply(scales, SCALE_BOUND)
-    Phi = codec.gc._Phi
+    Phi = gc._Phi
     y_lik = _LowerBound.apply(Phi((0.5 - a) / s) - Phi((-0.5 - a) / s), LIKELIHOOD_BOUND)
-    y_hat = SparseTensor(y.C, yout[0].t().contiguous(), 8)
+    return SparseTensor(y.C, yout[0].t().contiguous(), 8), y_lik, z_lik, Q_hat
+
+
+def forward_train(codec, coords, colors, Q_coords, Q_feats, noise):
+    """codec: oracle.codec.Codec built on leaf_state_dict(...) (``leaves=True``); noise(shape, coords) -> tensor, called per
+    hyperprior for z ([C, 1, N32]) then y ([1, C, N8]) with the points' coordinates (row order is implementation-specific); the
+    two-hyperprior variant (model/model.py:75-78) runs the latents' model first, then the q-map's."""
+    coords = oc.to_int_coords(coords)
+    N = coords.shape[0]
+    feats = torch.cat([torch.ones((N, 1)), torch.as_tensor(colors, dtype=torch.float32)], dim=1)
+    x = SparseTensor(coords, feats, 1)
+    Q = SparseTensor(oc.to_int_coords(Q_coords), torch.as_tensor(Q_feats, dtype=torch.float32), 1)
+    y, Q8, k = analysis(codec.p.sub("g_a"), x, Q, getattr(codec, "cfg_a", None))
+    if getattr(codec, "two", False):
+        y_hat, y_lik, zy_lik, _ = _hyper_train(codec.em_y.eb, codec.gc, codec.p.sub("entropy_model"), y, noise)
+        Q_hat, q_lik, zq_lik, _ = _hyper_train(codec.em_q.eb, codec.gc, codec.p.sub("entropy_model_map"), Q8, noise)
+        likelihoods = {"y": [y_lik, q_lik], "z": [zy_lik, zq_lik]}
+    else:
+        y_hat, y_lik, z_lik, Q_hat = _hyper_train(codec.eb, codec.gc, codec.p.sub("entropy_model"), y, noise, with_q=True)
+        likelihoods = {"y": y_lik, "z": z_lik}
     x_hat, points, preds = synthesis(codec.p.sub("g_s"), y_hat, Q_hat, k, coords=coords, cfg=getattr(codec, "cfg_s", None))
-    return {"prediction": x_hat, "points": points, "occ_predictions": preds, "likelihoods": {"y": y_lik, "z": z_lik}, "k": k}
+    return {"prediction": x_hat, "points": points, "occ_predictions": preds, "likelihoods": likelihoods, "k": k}
 
 
 def avg_pool(x, out_coords, out_stride):

@@ -29,9 +29,12 @@ def test_variant_models_construct_with_the_reference_parameter_sets(pcc):
     gone = base - abl
     assert gone and all(".cond_conv." in k for k in gone) and not (abl - base)
     assert {k.split(".cond_conv.")[0] for k in gone} == {"g_a", "g_s"}
-    two = dict(syn.OURS_CONFIG, entropy_model_map=syn.OURS_CONFIG["entropy_model"])
-    with pytest.raises(NotImplementedError):                 # model/model.py:22-24: no shipped config selects it
-        pcc.ColorModel(two)
+    # model/model.py:22-24: an "entropy_model_map" section selects two MeanScaleHyperprior models (tests/test_two_hyperprior.py);
+    # against the shipped model: h_q goes, a second h_a / h_s / entropy_bottleneck comes
+    two = {k for k, _ in pcc.ColorModel(syn.TWO_HYPERPRIOR_CONFIG).named_parameters()}
+    assert all(k.startswith("entropy_model.h_q.") for k in base - two) and base - two
+    assert all(k.startswith("entropy_model_map.") for k in two - base) and two - base
+    assert {k.split(".")[1] for k in two - base} == {"h_a", "h_s", "entropy_bottleneck"}
     bad = copy.deepcopy(syn.ABLATION_NOCONDITION_CONFIG)
     bad["g_a"]["condition_ablation"] = "something_else"
     m = pcc.ColorModel(bad)

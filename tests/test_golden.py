@@ -127,6 +127,39 @@ def test_kernel_order_oracle_reproduces_its_golden_bytes(pcc, oracle_codec):
         on.set_order(was)
 
 
+def test_two_hyperprior_oracle_reproduces_its_golden_bytes(pcc):
+    """The two-hyperprior variant (model/model.py:22-24, model/entropy_models.py:104-250) in "kernel" order: four streams, shapes, k,
+    latent coordinates and the decoded cloud equal the committed hashes (tests/test_two_hyperprior.py holds the HIP path to them)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    from make_golden import TWO_HYPERPRIOR_FRAMES, recon_sha
+    from oracle import nn as on
+    from oracle.codec import Codec
+    g = load("two_hyperprior_frames")
+    assert set(g) == set(TWO_HYPERPRIOR_FRAMES)
+    syn = pcc.synthetic
+    model = syn.make_model(seed=0, device="cpu", config=syn.TWO_HYPERPRIOR_CONFIG)
+    codec = Codec(model.state_dict(), syn.TWO_HYPERPRIOR_CONFIG)
+    codec.update()
+    assert float(codec.aux_loss()) > 0
+    was = on.set_order("kernel")
+    try:
+        for name, (shell, (qg, qa)) in TWO_HYPERPRIOR_FRAMES.items():
+            want = g[name]
+            pts = syn.sphere_shell(**shell)
+            qc, qf = syn.uniform_qmap(pts[:, :3], qg, qa)
+            strings, shape, k, coords = codec.compress(pts, qc, qf)
+            assert (pts.shape[0], k, shape) == (want["n_points"], want["k"], want["shape"]), name
+            flat = [strings[0][0][0], strings[0][1][0], strings[1][0][0], strings[1][1][0]]
+            assert [sha(b) for b in flat] == want["sha256"], name
+            assert want["q_symbols_min_max"][1] - want["q_symbols_min_max"][0] >= 8, "the q-map's symbols span several bins"
+            assert sha(np.ascontiguousarray(coords[oc.sort_order(coords)]).tobytes()) == want["latent_coords_sha256"], name
+            rec = codec.decompress(coords, strings, shape, k)
+            assert recon_sha(rec) == (want["recon_geometry_sha256"], want["recon_colour_sha256"]), name
+    finally:
+        on.set_order(was)
+
+
 def test_chain_convolution_equals_its_scalar_statement():
     """oracle/chain.c: the vectorised, windowed, threaded chain against the four-line scalar loop it restates, bit for bit,
     over thin / MFMA-order / narrow shapes, kernel sizes 1, 2, 3, sparse and dense neighbourhoods"""

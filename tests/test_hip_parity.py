@@ -219,6 +219,8 @@ CONV_SHAPES = [
     (4, 64, 3), (4, 2, 3), (2, 2, 3), (2, 128, 3), (2, 16, 3), (16, 2, 3), (1, 1, 3),
     # the remaining cin / 32 instantiations of the MFMA kernel (odd chunk counts alternate the LDS buffer parity)
     (96, 64, 3), (160, 32, 3), (224, 128, 3), (256, 128, 3),
+    # thin widths of a hyperprior over a narrow tensor (C * 3 / 2: the two-hyperprior variant's q-map model, tests/test_two_hyperprior.py)
+    (3, 4, 3), (6, 8, 3), (12, 16, 3), (24, 32, 3), (8, 3, 3),
 ]
 
 

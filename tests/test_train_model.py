@@ -35,8 +35,10 @@ def coord_noise_b(shape, coords):
 
 def _setup(pcc, geometry="sphere"):
     from pcc_amd import synthetic as syn
-    model = syn.make_model(seed=0, device=DEV)
-    if geometry == "sphere":
+    # "two_hyperprior": the variant model/model.py:22-24 builds from an "entropy_model_map" section (likelihood LISTS, a second
+    # hyperprior on the stride-8 q-map with 3-channel layers), on the sphere
+    model = syn.make_model(seed=0, device=DEV, config=syn.TWO_HYPERPRIOR_CONFIG if geometry == "two_hyperprior" else None)
+    if geometry in ("sphere", "two_hyperprior"):
         pts = syn.sphere_shell(**syn.CONFIG1)
     else:
         # irregular: a thick noisy shell plus scattered voxels (isolated rows, varied neighbour counts, sparse strided levels)
@@ -53,7 +55,7 @@ def _setup(pcc, geometry="sphere"):
     return model, pts, qc, qf, lam
 
 
-@pytest.mark.parametrize("geometry", ["sphere", "irregular"])
+@pytest.mark.parametrize("geometry", ["sphere", "irregular", "two_hyperprior"])
 def test_training_step_matches_oracle_autograd(pcc, geometry):
     from pcc_amd import entropy as pe
     from pcc_amd.loss import OURS_LOSS, Loss
@@ -80,9 +82,8 @@ def test_training_step_matches_oracle_autograd(pcc, geometry):
     assert len(gates) == len(gate_log) >= 40, (len(gates), len(gate_log))        # every activated layer once
 
     sd = ot.leaf_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-    codec = Codec(sd)
-    codec.sd, codec.p = sd, type(codec.p)(sd)
-    codec.eb = type(codec.eb)(codec.p.sub("entropy_model").sub("entropy_bottleneck"))
+    from pcc_amd import synthetic as syn
+    codec = Codec(sd, syn.TWO_HYPERPRIOR_CONFIG if geometry == "two_hyperprior" else None, leaves=True)
     on.FORCED_GATES, on.GATE_FLIPS = gates, []
     try:
         o_out = ot.forward_train(codec, qc, pts[:, 3:], qc, qf, coord_noise)
@@ -195,9 +196,7 @@ def test_training_step_batch_of_two_matches_oracle(pcc):
     total, parts = Loss(OURS_LOSS)(inp, out)
     total.backward()
     sd = ot.leaf_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-    codec = Codec(sd)
-    codec.sd, codec.p = sd, type(codec.p)(sd)
-    codec.eb = type(codec.eb)(codec.p.sub("entropy_model").sub("entropy_bottleneck"))
+    codec = Codec(sd, leaves=True)
     o_out = ot.forward_train(codec, qc, colors, qc, qf, coord_noise_b)
     o_total, o_parts = ot.losses(qc, colors, o_out, OSparseTensor(qc, torch.from_numpy(lam), 1))
     o_total.backward()

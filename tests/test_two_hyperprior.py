@@ -1,0 +1,205 @@
+"""GPU: the two-hyperprior variant of ColorModel (/root/reference/model/model.py:22-24 — an "entropy_model_map" section in the
+config: one ``MeanScaleHyperprior`` (model/entropy_models.py:104-250) codes y, a second one the stride-8 q-map; model.py:75-78,
+132-136, 197-201) against the oracle's restatement of it.
+
+No shipped yaml selects the variant; the widths of the q-map's model (2 -> 8, h_s widths 8, 8, 3, 4) are this build's choice
+(pcc_amd.synthetic.TWO_HYPERPRIOR_CONFIG) and exercise input widths the main configs never use (3 channels).
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import coords as oc
+from oracle import nn as on
+from oracle.codec import Codec, count_bits
+from oracle.metrics import pc_metrics
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def model(pcc):
+    m = pcc.synthetic.make_model(0, DEV, config=pcc.synthetic.TWO_HYPERPRIOR_CONFIG)
+    m.update()
+    return m
+
+
+@pytest.fixture(scope="module")
+def codec(pcc, model):
+    c = Codec({k: v.detach().cpu() for k, v in model.state_dict().items()}, pcc.synthetic.TWO_HYPERPRIOR_CONFIG)
+    c.update()
+    return c
+
+
+def flat(strings):
+    return [strings[0][0][0], strings[0][1][0], strings[1][0][0], strings[1][1][0]]       # y, z of the latents; y, z of the q-map
+
+
+def canonical(rec):
+    order = np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))
+    return rec[order, :3].astype(np.int32), np.rint(rec[order, 3:6] * 255.0).astype(np.uint8)
+
+
+def run_hip(pcc, model, pts, qc, qf):
+    x = torch.from_numpy(pts).to(DEV)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    strings, shape, k, coords = model.compress(x, Q)
+    rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k).cpu().numpy()
+    return strings, shape, k, coords.cpu().numpy(), rec
+
+
+def test_structure_of_the_variant(pcc, model):
+    """model/model.py:22-27,40-47: two MeanScaleHyperprior instances, aux_loss their sum, parameter names of the reference's module tree"""
+    assert type(model.entropy_model).__name__ == "MeanScaleHyperprior" and type(model.entropy_model_map).__name__ == "MeanScaleHyperprior"
+    assert not hasattr(model.entropy_model, "h_q")
+    names = set(model.state_dict())
+    for n in ("entropy_model_map.h_a.0.kernel", "entropy_model_map.h_s.6.bias", "entropy_model_map.entropy_bottleneck.quantiles",
+              "entropy_model.h_s.4.kernel"):
+        assert n in names, n
+    assert tuple(model.entropy_model_map.h_s[4].kernel.shape) == (8, 8, 3) and tuple(model.entropy_model_map.h_s[6].kernel.shape) == (27, 3, 4)
+    a, b = model.entropy_model.aux_loss(), model.entropy_model_map.aux_loss()
+    assert torch.equal(model.aux_loss(), a + b)
+    with pytest.raises(ValueError, match="stream pair"):
+        pts = pcc.synthetic.sphere_shell(**pcc.synthetic.CONFIG1)
+        qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3])
+        Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+        model.compress(torch.from_numpy(pts).to(DEV), Q, path="/tmp/never_written.bin")
+    with pytest.raises(ValueError, match="stream pair"):
+        model.decompress(path="/tmp/never_written.bin")
+
+
+@pytest.mark.parametrize("name", ["config1_32", "shell_64_q02_04"])
+def test_four_streams_and_reconstruction_equal_the_kernel_order_oracle_and_the_golden_hashes(pcc, model, codec, name):
+    from make_golden import TWO_HYPERPRIOR_FRAMES, recon_sha
+    with open(os.path.join(GOLD, "two_hyperprior_frames.json")) as f:
+        want = json.load(f)[name]
+    shell, (qg, qa) = TWO_HYPERPRIOR_FRAMES[name]
+    pts = pcc.synthetic.sphere_shell(**shell)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], qg, qa)
+    strings, shape, k, coords, rec = run_hip(pcc, model, pts, qc, qf)
+    assert (k, shape) == (want["k"], want["shape"])
+    assert [len(b) for b in flat(strings)] == want["len"]
+    assert [sha(b) for b in flat(strings)] == want["sha256"]
+    assert sha(np.ascontiguousarray(coords[oc.sort_order(coords)]).tobytes()) == want["latent_coords_sha256"]
+    assert recon_sha(rec) == (want["recon_geometry_sha256"], want["recon_colour_sha256"])
+    # and the oracle run here, in the same order: decoded latents value for value
+    was = on.set_order("kernel")
+    try:
+        o_strings, o_shape, o_k, o_coords = codec.compress(pts, qc, qf)
+        assert [bytes(b) for b in flat(o_strings)] == [bytes(b) for b in flat(strings)]
+        codec.decompress(o_coords, o_strings, o_shape, o_k)
+    finally:
+        on.set_order(was)
+    c8 = pcc.CoordMap(torch.from_numpy(coords).to(DEV).to(torch.int32).contiguous(), 8, nbatch=1)
+    from pcc_amd.entropy_models import _canonical_map
+    points = [_canonical_map(c8, 8), _canonical_map(c8.down().down(), 32)]
+    with torch.no_grad():
+        y_hat = model.entropy_model.decompress(points, strings[0], shape[0])
+        Q_hat = model.entropy_model_map.decompress(points, strings[1], shape[1])
+    o_y, o_Q = codec.last_dec["y_hat"], codec.last_dec["Q_hat"]
+    assert np.array_equal(y_hat.C.cpu().numpy(), o_y.C) and np.array_equal(Q_hat.C.cpu().numpy(), o_Q.C)
+    assert torch.equal(y_hat.F.cpu(), o_y.F) and torch.equal(Q_hat.F.cpu(), o_Q.F)
+    assert Q_hat.F.shape[1] == 2 and float(Q_hat.F.abs().max()) > 2.0          # the q-map really went through a quantiser
+
+
+def test_larger_frame_within_the_contract_of_the_blas_order_oracle(pcc, model, codec):
+    """a 128^3 shell (N = 55 k): kernel-order equality of the streams, and the independent BLAS-order oracle within BASELINE's
+    tolerances (bpp 1e-3, D1 / Y PSNR 1e-3 dB) when no symbol is rounded differently"""
+    pts = pcc.synthetic.sphere_shell(grid=128, radius=55.0, half_width=0.6)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.4, 0.8)
+    strings, shape, k, coords, rec = run_hip(pcc, model, pts, qc, qf)
+    was = on.set_order("kernel")
+    try:
+        e_strings, e_shape, e_k, e_coords = codec.compress(pts, qc, qf)
+        e_rec = codec.decompress(e_coords, e_strings, e_shape, e_k)
+    finally:
+        on.set_order(was)
+    assert (e_shape, e_k) == (shape, k)
+    assert [bytes(b) for b in flat(e_strings)] == [bytes(b) for b in flat(strings)]
+    g, c = canonical(rec)
+    eg, ec = canonical(e_rec)
+    assert np.array_equal(g, eg) and np.array_equal(c, ec)
+    b_strings, b_shape, b_k, b_coords = codec.compress(pts, qc, qf)
+    b_rec = codec.decompress(b_coords, b_strings, b_shape, b_k)
+    assert (b_shape, b_k) == (shape, k)
+    n = pts.shape[0]
+    m_h, m_b = pc_metrics(pts, rec, 127), pc_metrics(pts, b_rec, 127)
+    d_bpp = abs(count_bits(strings) - count_bits(b_strings)) / n
+    d_d1, d_y = abs(m_h["sym_psnr_mse"] - m_b["sym_psnr_mse"]), abs(float(m_h["sym_y_psnr"]) - float(m_b["sym_y_psnr"]))
+    same = [bytes(a) == bytes(b) for a, b in zip(flat(strings), flat(b_strings))]
+    print({"n": n, "bpp": count_bits(strings) / n, "d_bpp": d_bpp, "d_d1_db": d_d1, "d_y_db": d_y, "streams_equal_blas": same})
+    if all(same):
+        assert d_d1 <= 1e-3 and d_y <= 1e-3
+    else:
+        assert d_bpp <= 1e-3 and d_d1 <= 0.05 and d_y <= 0.05            # a latent a step apart (tests/_parity.py's rule)
+
+
+def test_eval_forward_equals_the_kernel_order_oracle(pcc, model, codec):
+    """model/model.py:51-93 with the variant's likelihood lists {"y": [L_y, L_Q], "z": [L_zy, L_zQ]} (:75-78): reconstruction features and
+    occupancy logits equal value for value (both hyperpriors' quantised outputs feed them)"""
+    pts = pcc.synthetic.sphere_shell(grid=64, radius=27.0, half_width=0.6)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.3, 0.6)
+    coords = np.concatenate([np.zeros((pts.shape[0], 1), np.float32), pts[:, :3]], axis=1)
+    x = pcc.SparseTensor(coordinates=torch.from_numpy(coords).to(DEV), features=torch.from_numpy(pts[:, 3:6]).to(DEV), device=DEV)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    with torch.no_grad():
+        out = model(x, Q, None)
+    was = on.set_order("kernel")
+    try:
+        ref = codec.forward_eval(coords, pts[:, 3:6], qc, qf)
+    finally:
+        on.set_order(was)
+    assert isinstance(out["likelihoods"]["y"], list) and len(out["likelihoods"]["y"]) == 2 and len(out["likelihoods"]["z"]) == 2
+    for key in ("y", "z"):
+        for got, want in zip(out["likelihoods"][key], ref["likelihoods"][key]):
+            assert tuple(got.shape) == tuple(want.shape)
+    # the likelihoods pass through erfc / exp / tanh, which the two sides take from different math libraries (tests/test_exact_parity.py):
+    # total bits to 1e-6 relative; everything that is convolution arithmetic is compared for equality below
+    bits = lambda L: float(-torch.log2(L.double()).sum())
+    for key in ("y", "z"):
+        for got, want in zip(out["likelihoods"][key], ref["likelihoods"][key]):
+            assert abs(bits(got.cpu()) - bits(want)) <= 1e-6 * bits(want) + 1e-3, (key, bits(got.cpu()), bits(want))
+    pc, pf = out["prediction"].C.cpu().numpy(), out["prediction"].F.cpu().numpy()
+    rc, rf = ref["prediction"].C, ref["prediction"].F.numpy()
+    og, orf = oc.sort_order(pc), oc.sort_order(rc)
+    assert np.array_equal(pc[og], rc[orf]) and np.array_equal(pf[og], rf[orf])
+    for got, want in zip(out["occ_predictions"], ref["occ_predictions"]):
+        gc_, gf = got.C.cpu().numpy(), got.F.cpu().numpy()
+        a, b = oc.sort_order(gc_), oc.sort_order(want.C)
+        assert np.array_equal(gc_[a], want.C[b]) and np.array_equal(gf[a][:, 0], want.F.numpy()[b][:, 0])
+
+
+def test_training_step_runs_and_reaches_both_entropy_models(pcc):
+    """train mode (noise quantisation, model/entropy_models.py:145-169): a loss over all four likelihood tensors and the colours
+    back-propagates through the HIP kernels into both hyperpriors, incl. the 3-channel layers of the q-map's h_s"""
+    model = pcc.synthetic.make_model(0, DEV, config=pcc.synthetic.TWO_HYPERPRIOR_CONFIG).train()
+    pts = pcc.synthetic.sphere_shell(**pcc.synthetic.CONFIG1)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    coords = np.concatenate([np.zeros((pts.shape[0], 1), np.float32), pts[:, :3]], axis=1)
+    x = pcc.SparseTensor(coordinates=torch.from_numpy(coords).to(DEV), features=torch.from_numpy(pts[:, 3:6]).to(DEV), device=DEV)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc).to(DEV), features=torch.from_numpy(qf).to(DEV), device=DEV)
+    torch.manual_seed(0)
+    out = model(x, Q, None)
+    n = pts.shape[0]
+    bits = sum(torch.log(l).sum() for key in ("y", "z") for l in out["likelihoods"][key]) / (-np.log(2) * n)
+    loss = bits + (out["prediction"].F ** 2).mean() + model.aux_loss()
+    assert torch.isfinite(loss)
+    loss.backward()
+    params = dict(model.named_parameters())
+    grads = {nm: params[nm].grad for nm in ("entropy_model_map.h_s.6.kernel", "entropy_model_map.h_s.4.kernel", "entropy_model_map.h_a.0.kernel",
+                                            "entropy_model_map.entropy_bottleneck._matrix0", "entropy_model.h_s.6.kernel")}
+    grads["g_a.condition_encoder.down_layers[2]"] = model.g_a.condition_encoder.down_layers[2].kernel.grad      # what the q-map's model codes
+    for nm, g in grads.items():
+        assert g is not None and torch.isfinite(g).all() and float(g.abs().max()) > 0, nm
