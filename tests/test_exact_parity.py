@@ -157,6 +157,17 @@ def test_full_config2_frame_equals_the_kernel_order_oracle(pcc, model, oracle_co
     exact_compare(pcc, model, oracle_codec, pts, qc, qf, "config 2, full size")
 
 
+@pytest.mark.skipif(os.environ.get("PCC_TEST_FULL") != "1", reason="one-off (PCC_TEST_FULL=1): ~5 minutes of oracle; its log is profiles/r04_exact_parity_vox11_sized_frame.log")
+def test_vox11_sized_frame_equals_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order):
+    """a 2048^3 shell of ~3.4 M points (four times config 2; the size of an 11-bit 8iVFB-style frame): the up blocks' candidate
+    sets pass 20 M rows, their 64-channel tensors 4 GiB — the 64-bit-addressed convolution kernel, the large-set sort and map
+    paths — and every stream byte, latent, voxel and colour still equals the oracle's"""
+    pts = pcc.synthetic.sphere_shell(grid=2048, radius=520.0, half_width=0.5)
+    assert pts.shape[0] > 3_000_000
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    exact_compare(pcc, model, oracle_codec, pts, qc, qf, f"2048^3 shell, N={pts.shape[0]}")
+
+
 @pytest.mark.parametrize("cfg", [dict(grid=32, radius=15.0, half_width=0.875), dict(grid=64, radius=27.0, half_width=0.6)])
 def test_eval_forward_tensors_equal_the_kernel_order_oracle(pcc, model, oracle_codec, kernel_order, cfg):
     """ColorModel.forward in eval mode (model/model.py:51-93): everything it returns that is convolution arithmetic — the
