@@ -1306,21 +1306,34 @@ static int launch_mfma_x3(const ConvArgs& a, hipStream_t st) {
     return PCC_ERR_UNSUPPORTED;
 }
 
+template <int CIN, int CPT>
+static int launch_thin_cpt(const ConvArgs& a, unsigned nb, size_t lds, hipStream_t st) {
+    auto kern = conv_thin_kernel<CIN, CPT>;
+    if (lds > 64 * 1024) {                        // beyond the default dynamic-LDS limit (24 -> 32 with 27 offsets: 81 KB)
+        static bool attr_set = false;
+        if (!attr_set) {
+            PCC_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), lds, st, a);
+    PCC_LAUNCH_CHECK();
+    return PCC_OK;
+}
+
 template <int CIN>
 static int launch_thin(const ConvArgs& a, hipStream_t st) {
     const size_t lds = (size_t)a.K * CIN * a.cout * sizeof(float);
-    PCC_REQUIRE(lds <= 64 * 1024, "conv(thin): weights %zu B exceed LDS budget (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
+    PCC_REQUIRE(lds <= 160 * 1024, "conv(thin): weights %zu B exceed the 160 KB of LDS (cin=%d cout=%d K=%d)", lds, CIN, a.cout, a.K);
     // channels per thread: the largest of 8, 4, 2, 1 dividing cout
     const int cpt = (a.cout % 8 == 0) ? 8 : (a.cout % 4 == 0) ? 4 : (a.cout % 2 == 0) ? 2 : 1;
     // every block stages the whole weight tensor into LDS first (27.6 KB for 2 -> 128): a few resident blocks per CU
     // that stride over the rows, not one block per 256 outputs
     const unsigned nb = blocks_for(a.n_out * (a.cout / cpt), 256, lds >= 4096 ? 2048u : (1u << 20));
-    if (cpt == 8) hipLaunchKernelGGL((conv_thin_kernel<CIN, 8>), dim3(nb), dim3(256), lds, st, a);
-    else if (cpt == 4) hipLaunchKernelGGL((conv_thin_kernel<CIN, 4>), dim3(nb), dim3(256), lds, st, a);
-    else if (cpt == 2) hipLaunchKernelGGL((conv_thin_kernel<CIN, 2>), dim3(nb), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((conv_thin_kernel<CIN, 1>), dim3(nb), dim3(256), lds, st, a);
-    PCC_LAUNCH_CHECK();
-    return PCC_OK;
+    if (cpt == 8) return launch_thin_cpt<CIN, 8>(a, nb, lds, st);
+    if (cpt == 4) return launch_thin_cpt<CIN, 4>(a, nb, lds, st);
+    if (cpt == 2) return launch_thin_cpt<CIN, 2>(a, nb, lds, st);
+    return launch_thin_cpt<CIN, 1>(a, nb, lds, st);
 }
 
 }  // namespace pcc
