@@ -272,7 +272,8 @@ int pcc_compact_rows(const uint8_t* mask, int64_t n, const int32_t* coords, int3
  * Per-batch top-k on one logit per row (GenerativeUpBlock._topk_prediction,
  * model/blocks.py:130-150, torch.topk).  Row i belongs to batch coords[i*4]; batch b keeps
  * its k[b] largest logits (logits[i*ld]); exact ties are broken by ascending voxel key.
- * NaN sorts above +inf (torch.topk).  state: >= pcc_topk_state_elems(nbatch) int32 elements.
+ * NaN sorts above +inf (torch.topk).  state: >= pcc_topk_state_elems(nbatch) int32 elements (per item the selection's words and a
+ * 256-bin histogram; for one item also the 256 x 256 per-workgroup bins of the logit passes).
  * ------------------------------------------------------------------------------------- */
 int64_t pcc_topk_state_elems(int32_t nbatch);
 int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_t n, int32_t nbatch,

@@ -112,6 +112,119 @@ __global__ __launch_bounds__(256) void topk_hist(const float* __restrict__ logit
     }
 }
 
+// One batch item, passes 0-3 (the four bytes of the logit key).  topk_hist ends with every workgroup adding its bins to the SAME 256
+// global words: same-address atomics from eight XCDs are performed one after the other at the memory side — ~60 ns each, 512 groups
+// = 30-35 us per pass whatever the row count (a pass over 233 k rows took as long as one over 1.26 M).  Here a group STORES its 256
+// bins as a row of `partial` and the pick sums the rows.
+constexpr int TK1_GROUPS = 256;        // x 1024 threads; 512: the pick's sum over the groups' rows costs more than the pass gains
+constexpr int TK1_THREADS = 1024;
+__global__ __launch_bounds__(TK1_THREADS) void topk_hist1_kernel(const float* __restrict__ logits, int ld, int64_t n, int pass,
+                                                         const int32_t* __restrict__ st, int32_t* __restrict__ partial) {
+    __shared__ int lh[256];
+    if (st[1] != 0) return;                       // resolved (or k <= 0)
+    if (threadIdx.x < 256) lh[threadIdx.x] = 0;
+    __syncthreads();
+    // four rows per thread and iteration, their loads issued together
+    const uint32_t pmask = top_bytes_mask(pass, 0), pref = (uint32_t)st[3] & pmask;
+    const int shift = 8 * (3 - pass);
+    const int64_t stride = (int64_t)gridDim.x * TK1_THREADS;
+    for (int64_t i0 = (int64_t)blockIdx.x * TK1_THREADS + threadIdx.x; i0 < n; i0 += 4 * stride) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t i = i0 + u * stride;
+            v[u] = (i < n) ? logits[i * ld] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t kw = float_key(v[u]);
+            const bool on = (i0 + u * stride < n) && ((kw & pmask) == pref);
+            const uint32_t digit = (kw >> shift) & 0xFFu;
+            const uint64_t same = match_digit(digit, on);        // (see topk_hist: one LDS atomic per distinct digit and wave)
+            if (on && (same & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicAdd(&lh[digit], __popcll(same));
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 256) partial[(int64_t)blockIdx.x * 256 + threadIdx.x] = lh[threadIdx.x];
+}
+
+// topk_pick for one batch item on the groups' bins: 1024 threads, thread (q, d) sums bin d over a quarter of the rows of `partial`
+__global__ __launch_bounds__(1024) void topk_pick1_kernel(int pass, int32_t* __restrict__ st, const int32_t* __restrict__ partial, int groups) {
+    __shared__ int hq[4][256];
+    __shared__ int h[256];
+    __shared__ int total_s;
+    if (st[1] != 0) return;
+    const int d = threadIdx.x & 255, q = threadIdx.x >> 8;
+    int sum = 0;
+    for (int g = q; g < groups; g += 4) sum += partial[(int64_t)g * 256 + d];
+    hq[q][d] = sum;
+    __syncthreads();
+    if (q == 0) h[d] = hq[0][d] + hq[1][d] + hq[2][d] + hq[3][d];
+    __syncthreads();
+    const int krem = st[0];
+    int above = 0;
+    if (q == 0) {
+        for (int j = d + 1; j < 256; ++j) above += h[j];
+        if (d == 0) total_s = above + h[0];
+    }
+    __syncthreads();
+    if (q != 0) return;
+    if (pass == 0 && total_s <= krem) {
+        if (d == 0) { st[1] = 1; st[2] = 0; }      // no more than k rows: keep them all
+        return;
+    }
+    if (above < krem && krem <= above + h[d]) {
+        st[3] = (int32_t)((uint32_t)st[3] | ((uint32_t)d << (8 * (3 - pass))));
+        const int knew = krem - above;
+        st[0] = knew;
+        if (h[d] == knew) { st[1] = 1; st[2] = pass + 1; }
+    }
+}
+
+// One batch item, passes 4-11 (the eight bytes of the tie-break key) in ONE workgroup: they run only when rows with EXACTLY the
+// boundary logit straddle the k-th place; otherwise this launch returns at once — it replaces sixteen dispatches that did.  The
+// slow case walks all rows eight times at one CU's rate (a frame of equal logits: milliseconds instead of microseconds, same mask).
+__global__ __launch_bounds__(1024) void topk_tail_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ coords,
+                                                         int64_t n, int32_t* __restrict__ state) {
+    __shared__ int32_t st[8];
+    __shared__ int h[256];
+    const int t = threadIdx.x;
+    if (state[1] != 0) return;
+    if (t < 8) st[t] = state[t];
+    __syncthreads();
+    for (int pass = 4; pass < 12; ++pass) {
+        if (st[1]) break;                              // uniform: st is only written between barriers
+        if (t < 256) h[t] = 0;
+        __syncthreads();
+        for (int64_t i = t; i < n; i += 1024) {
+            // the logit alone decides for almost every row: the coordinates are read for the rows on the boundary only
+            if (float_key(logits[i * ld]) != (uint32_t)st[3]) continue;
+            const int4 c = reinterpret_cast<const int4*>(coords)[i];
+            if (c.x != 0) continue;
+            const Key96 key = make_key(logits[i * ld], c);
+            if (cmp_prefix(key, st, pass) != 0) continue;
+            atomicAdd(&h[(key.w[pass >> 2] >> (8 * (3 - (pass & 3)))) & 0xFFu], 1);
+        }
+        __syncthreads();
+        const int krem = st[0];
+        int above = 0, mine = 0;
+        if (t < 256) {
+            mine = h[t];
+            for (int j = t + 1; j < 256; ++j) above += h[j];
+        }
+        __syncthreads();
+        if (t < 256 && above < krem && krem <= above + mine) {
+            const int word = pass >> 2, shift = 8 * (3 - (pass & 3));
+            st[3 + word] = (int32_t)((uint32_t)st[3 + word] | ((uint32_t)t << shift));
+            const int knew = krem - above;
+            st[0] = knew;
+            if (mine == knew || pass == 11) { st[1] = 1; st[2] = pass + 1; }
+        }
+        __syncthreads();
+    }
+    if (t < 8) state[t] = st[t];
+}
+
 __global__ __launch_bounds__(256) void topk_pick(int pass, int32_t* __restrict__ state) {
     __shared__ int h[256];
     __shared__ int total_s;
@@ -527,7 +640,7 @@ int pcc_small_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_
     return PCC_OK;
 }
 
-int64_t pcc_topk_state_elems(int32_t nbatch) { return (int64_t)nbatch * TK_STRIDE; }
+int64_t pcc_topk_state_elems(int32_t nbatch) { return (int64_t)nbatch * TK_STRIDE + (nbatch == 1 ? (int64_t)TK1_GROUPS * 256 : 0); }
 
 int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_t n, int32_t nbatch, const int32_t* k,
                   uint8_t* mask, int32_t* state, void* stream) {
@@ -541,7 +654,22 @@ int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_
     }
     hipLaunchKernelGGL(topk_init, dim3(nbatch), dim3(256), 0, st, k, nbatch, state);
     if (n > 0) {
-        const unsigned nb = blocks_for(n, 256, 2048);
+        // 512 workgroups, not more: every group ends with up to 256 atomic adds on the SAME global bins, which serialise
+        // (one item, 5.16 M rows, four passes: 335 us with 2048 groups, 236 with 512, 303 with 256 — fewer groups read the rows slower)
+        const unsigned nb = blocks_for(n, 256, 512);
+        if (nbatch == 1 && small_path_enabled(1)) {            // PCC_TOPK_SMALL=0: the separate launches (A/B)
+            const unsigned groups = blocks_for(n, TK1_THREADS * 4, TK1_GROUPS);
+            int32_t* partial = state + TK_STRIDE;
+            for (int pass = 0; pass < 4; ++pass) {
+                hipLaunchKernelGGL(topk_hist1_kernel, dim3(groups), dim3(TK1_THREADS), 0, st, logits, ld, n, pass, state, partial);
+                hipLaunchKernelGGL(topk_pick1_kernel, dim3(1), dim3(1024), 0, st, pass, state, partial, (int)groups);
+            }
+            hipLaunchKernelGGL(topk_tail_kernel, dim3(1), dim3(1024), 0, st, logits, ld, coords, n, state);
+            hipLaunchKernelGGL(topk_write_mask, dim3(blocks_for(n, 256)), dim3(256), 0, st, logits, ld, coords, n, nbatch,
+                               state, mask);
+            PCC_LAUNCH_CHECK();
+            return PCC_OK;
+        }
         for (int pass = 0; pass < 12; ++pass) {
             hipLaunchKernelGGL(topk_hist, dim3(nb), dim3(256), 0, st, logits, ld, coords, n, nbatch, pass, state);
             hipLaunchKernelGGL(topk_pick, dim3(nbatch), dim3(256), 0, st, pass, state);

@@ -441,6 +441,35 @@ def test_topk_mask(pcc, nbatch):
         assert (got == want).all(), (ks, int(got.sum()), int(want.sum()))
 
 
+@pytest.mark.parametrize("ties", ["some", "none", "all", "two_values"])
+def test_topk_mask_of_a_large_single_item(pcc, ties):
+    """beyond the one-workgroup size (32,768 rows), one batch item: four fused (histogram + pick) launches over the logit bytes and
+    ONE tail launch for the eight bytes of the coordinate tie-break — which only has work when rows with exactly the boundary logit
+    straddle the k-th place ("some", "two_values") or every row does ("all")"""
+    from pcc_amd import sparse as sp
+    from oracle.codec import topk_mask
+    rng = np.random.default_rng(12)
+    n = 150_001
+    flat = rng.choice(200 ** 3, size=n, replace=False)
+    c = np.stack([np.zeros(n, np.int64), flat // 40000 - 100, (flat // 200) % 200, flat % 200], axis=1).astype(np.int32)
+    logits = rng.normal(size=(n, 2)).astype(np.float32)
+    if ties == "some":
+        logits[rng.integers(0, n, n // 3), 0] = 0.25
+        logits[rng.integers(0, n, 500), 0] = -0.0
+        logits[rng.integers(0, n, 500), 0] = 0.0
+    elif ties == "all":
+        logits[:, 0] = -1.5
+    elif ties == "two_values":
+        logits[:, 0] = np.where(rng.random(n) < 0.5, 2.0, -2.0).astype(np.float32)
+    n_quarter = int((logits[:, 0] == 0.25).sum())
+    n_above = int((logits[:, 0] > 0.25).sum())
+    for k in (n // 3, 1, n + 5, 0, n, n_above + max(1, n_quarter // 2), n_above, n_above + 1, n - 1):
+        got = sp.topk_mask(dev(logits), dev(c), [k], 1).cpu().numpy().astype(bool)
+        want = topk_mask(on.SparseTensor(c, torch.from_numpy(logits), 1), [k])
+        assert int(got.sum()) == min(k, n), (ties, k, int(got.sum()))
+        assert (got == want).all(), (ties, k, int((got != want).sum()))
+
+
 def test_sort_permutation(pcc):
     c = shell_coords(pcc, batch=3, seed=1)
     perm = pcc.CoordMap(dev(c), 1).sort_permutation().cpu().numpy()
