@@ -487,7 +487,7 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void order_small_kernel(const uin
     order_bit_positions(cnt27, pos_s);
     for (int i = t; i < n; i += RS_SMALL_THREADS) keys_a[i] = order_key_of(row_mask[i] & 0x7FFFFFFu, pos_s);
     __syncthreads();
-    radix_sort_small_body<uint32_t, ROUNDS>(keys_a, keys_b, va, vb, 1, n, 0, 27, 4);
+    radix_sort_small_body<uint32_t, ROUNDS, 9>(keys_a, keys_b, va, vb, 1, n, 0, 27, 3);      // 27 bits = three 9-bit passes: the result ends in the b-side
 }
 
 // ---- a small kernel map and its execution order in ONE launch -----------------------------------------------------------
@@ -580,8 +580,8 @@ __global__ __launch_bounds__(RS_SMALL_THREADS) void small_map_kernel(const int32
     order_bit_positions(cnt27, pos_s);
     for (int i = t; i < n; i += RS_SMALL_THREADS) keys_a[i] = order_key_of(rm[i] & 0x7FFFFFFu, pos_s);
     __syncthreads();
-    // 27 key bits = four 8-bit passes: the sorted values (the rows, from an iota) end in the a-side = `order`
-    radix_sort_small_body<uint32_t, ROUNDS>(keys_a, keys_b, order, vals_x, 1, n, 0, 27, 4);
+    // 27 key bits = three 9-bit passes: the sorted values (the rows, from an iota) end in the b-side = `order`
+    radix_sort_small_body<uint32_t, ROUNDS, 9>(keys_a, keys_b, vals_x, order, 1, n, 0, 27, 3);
     // group masks (positions are consecutive across a wave's lanes)
     for (int i0 = 0; i0 < n; i0 += RS_SMALL_THREADS) {
         const int i = i0 + t;
@@ -700,11 +700,11 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     void* counters = p;
     uint32_t* bit_counts = reinterpret_cast<uint32_t*>(p + radix_sort_counter_bytes(n));       // 27 words in the scratch's 256-byte tail
     if (small_path_enabled(0) && block_log2 < 0 && n <= RS_SMALL_N) {      // PCC_ORDER_SMALL=0: never (A/B)
-        // counts + keys + sort in one workgroup (27 key bits = four passes: the sorted rows end in the a-side = `order`)
+        // counts + keys + sort in one workgroup (27 key bits = three 9-bit passes: the sorted rows end in the b-side = `order`)
         const int rounds = (int)(((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
         uint32_t* ka = reinterpret_cast<uint32_t*>(keys_a);
         uint32_t* kb = reinterpret_cast<uint32_t*>(keys_b);
-#define PCC_ORDER_SMALL(R) hipLaunchKernelGGL(order_small_kernel<R>, dim3(1), dim3(RS_SMALL_THREADS), 0, st, row_mask, (int)n, ka, kb, order, vals_x)
+#define PCC_ORDER_SMALL(R) hipLaunchKernelGGL(order_small_kernel<R>, dim3(1), dim3(RS_SMALL_THREADS), 0, st, row_mask, (int)n, ka, kb, vals_x, order)
         if (rounds <= 1) PCC_ORDER_SMALL(1);
         else if (rounds <= 2) PCC_ORDER_SMALL(2);
         else if (rounds <= 4) PCC_ORDER_SMALL(4);
@@ -718,8 +718,9 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
     PCC_CHECK_HIP(hipMemsetAsync(bit_counts, 0, 27 * sizeof(uint32_t), st));
     hipLaunchKernelGGL(mask_bit_counts_kernel, dim3(blocks_for(n, 256 * 16, 512)), dim3(256), 0, st, row_mask, n, bit_counts);
     const int begin = 0, end = block_log2 >= 0 ? 64 : 27;
+    const int digit_bits = block_log2 >= 0 ? 8 : radix_sort_order_digit_bits(n);      // 27 bits: three 9-bit passes instead of four 8-bit ones
     // the sorted values must land in `order`: they end in the b-side when the pass count is odd
-    const bool in_b = radix_sort_result_in_b(begin, end);
+    const bool in_b = radix_sort_result_in_b(begin, end, digit_bits);
     int32_t* va = in_b ? vals_x : order;
     int32_t* vb = in_b ? order : vals_x;
     int rc;
@@ -727,7 +728,7 @@ int pcc_order_rows_by_mask(const uint32_t* row_mask, const int32_t* coords, int6
         hipLaunchKernelGGL(order_keys32_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, n, bit_counts,
                            reinterpret_cast<uint32_t*>(keys_a));
         rc = radix_sort_pairs_u32(reinterpret_cast<uint32_t*>(keys_a), reinterpret_cast<uint32_t*>(keys_b), va, vb, true, n, begin, end,
-                                  counters, st);
+                                  counters, st, digit_bits);
     } else {
         hipLaunchKernelGGL(order_keys64_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, st, row_mask, coords, n, block_log2, tensor_stride,
                            bit_counts, reinterpret_cast<uint64_t*>(keys_a));

@@ -19,14 +19,16 @@ int scan_flags(const int32_t* flags, int64_t m, int32_t* pos, int32_t* block_sum
 // --- radix sort (sort.hip) --------------------------------------------------------------------------
 // Sorts n pairs by bits [begin_bit, end_bit) of the key, ascending, stable.  keys_a / vals_a hold the input and
 // are used as ping-pong space together with keys_b / vals_b; the sorted pairs end up in the *_a arrays when the
-// number of 8-bit passes is even and in the *_b arrays when it is odd — radix_sort_result_in_b() tells which.
+// number of passes is even and in the *_b arrays when it is odd — radix_sort_result_in_b() tells which.
 // vals_a == NULL on entry means "values = 0 .. n-1" (they are then materialised by the first pass).
 // counters: radix_sort_counter_bytes(n) bytes of scratch.
-int radix_sort_passes(int begin_bit, int end_bit);
-static inline bool radix_sort_result_in_b(int begin_bit, int end_bit) { return radix_sort_passes(begin_bit, end_bit) & 1; }
+// digit_bits: 8, or 9 (32-bit keys only: the 27-bit execution-order keys sort in three passes instead of four).
+int radix_sort_passes(int begin_bit, int end_bit, int digit_bits = 8);
+static inline bool radix_sort_result_in_b(int begin_bit, int end_bit, int digit_bits = 8) { return radix_sort_passes(begin_bit, end_bit, digit_bits) & 1; }
 int64_t radix_sort_counter_bytes(int64_t n);
+int radix_sort_order_digit_bits(int64_t n);      // digit width the 27-bit execution-order sort of n keys should use
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, int32_t* vals_a, int32_t* vals_b, bool vals_are_iota, int64_t n,
-                         int begin_bit, int end_bit, void* counters, hipStream_t st);
+                         int begin_bit, int end_bit, void* counters, hipStream_t st, int digit_bits = 8);
 int radix_sort_pairs_u64(uint64_t* keys_a, uint64_t* keys_b, int32_t* vals_a, int32_t* vals_b, bool vals_are_iota, int64_t n,
                          int begin_bit, int end_bit, void* counters, hipStream_t st);
 

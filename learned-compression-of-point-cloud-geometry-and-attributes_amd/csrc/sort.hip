@@ -1,4 +1,5 @@
-// Stable LSD radix sort of (key, int32 value) pairs, 8-bit digits, written for 64-wide wavefronts.
+// Stable LSD radix sort of (key, int32 value) pairs, 8-bit digits (9-bit for the 27-bit execution-order keys: three passes
+// instead of four), written for 64-wide wavefronts.
 //
 // Used for the MFMA execution order of a kernel map (32-bit key: neighbour-mask popcount | 27-bit mask; up to
 // 5 M rows per coordinate set), the canonical (b, x, y, z) order of the latents (utils.sort_tensor /
@@ -28,18 +29,20 @@ constexpr int RS_MID_ITEMS = 8;                   // keys per lane: 2048-key wor
 constexpr int RS_MID_MAX_UNITS = 64;              // n <= 131,072 (a thread sums its digit's row of unit counters itself: 265 k rows took 150 us this way, 850 k rows 132 us the other)
 constexpr int RS_BIG_ITEMS = 16;                  // 4096-key workgroups (48 KB of LDS for 64-bit keys: three per CU), row-scan kernel between count and scatter
 
-template <class K, int ROUNDS>
+template <class K, int ROUNDS, int DB>
 __global__ __launch_bounds__(RS_SMALL_THREADS) void radix_sort_small_kernel(K* ka, K* kb, int32_t* va, int32_t* vb, int iota, int n,
                                                                            int begin_bit, int end_bit, int passes) {
-    radix_sort_small_body<K, ROUNDS>(ka, kb, va, vb, iota, n, begin_bit, end_bit, passes);
+    radix_sort_small_body<K, ROUNDS, DB>(ka, kb, va, vb, iota, n, begin_bit, end_bit, passes);
 }
 
 // counts[d * nunits + u] = number of keys of workgroup u (256 * ITEMS consecutive keys) with digit d
-template <class K, int ITEMS>
+template <class K, int ITEMS, int DB>
 __global__ __launch_bounds__(256) void radix_count_kernel(const K* __restrict__ keys, int64_t n, int shift, unsigned dmask,
                                                           int64_t nunits, int32_t* __restrict__ counts) {
-    __shared__ int cnt[256];
-    cnt[threadIdx.x] = 0;
+    constexpr int ND = 1 << DB;
+    __shared__ int cnt[ND];
+#pragma unroll
+    for (int d = threadIdx.x; d < ND; d += 256) cnt[d] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (256 * ITEMS);
     K key[ITEMS];
@@ -52,7 +55,8 @@ __global__ __launch_bounds__(256) void radix_count_kernel(const K* __restrict__ 
     for (int j = 0; j < ITEMS; ++j)
         if (base + (int64_t)j * 256 + threadIdx.x < n) atomicAdd(&cnt[(unsigned)(key[j] >> shift) & dmask], 1);
     __syncthreads();
-    counts[(int64_t)threadIdx.x * nunits + blockIdx.x] = cnt[threadIdx.x];
+#pragma unroll
+    for (int d = threadIdx.x; d < ND; d += 256) counts[(int64_t)d * nunits + blockIdx.x] = cnt[d];
 }
 
 // one workgroup per digit: exclusive scan of the digit's row of `nunits` counters in place, row sum -> totals[digit]
@@ -100,21 +104,22 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(int32_t* __restrict_
 // to 64 different lines per instruction, each (wave, digit) cursor advancing 4 bytes at a time over 32 rounds: with 4096
 // waves x 256 cursors x 2 arrays in flight the partially written lines (256 MB) fell out of the 32 MB of L2 long before
 // they were full, and a 5.16 M-pair pass took 0.42 ms for 82 MB (0.2 TB/s).
-template <class K, int ITEMS, bool SELF_PREFIX>
+template <class K, int ITEMS, bool SELF_PREFIX, int DB>
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict__ src, K* __restrict__ dst, const int32_t* __restrict__ vs,
                                                             int32_t* __restrict__ vd, int iota, int64_t n, int shift, unsigned dmask,
                                                             int64_t nunits, const int32_t* __restrict__ counts,
                                                             const int32_t* __restrict__ totals) {
     constexpr int WAVE_KEYS = 64 * ITEMS, WG_KEYS = 4 * WAVE_KEYS;
+    constexpr int ND = 1 << DB, DH = ND / 256;       // digits; digits per thread (digit h * 256 + t, h < DH: ascending with (h, t))
     __shared__ K skey[WG_KEYS];
     __shared__ int32_t sval[WG_KEYS];
-    __shared__ int cnt[4][256];          // per wave: digit counts, then the wave's cursor into the local order
-    __shared__ int lbase[256];           // first local position of a digit
-    __shared__ int gbase[256];           // global position of the digit's first pair of this workgroup
+    __shared__ int cnt[4][ND];           // per wave: digit counts, then the wave's cursor into the local order
+    __shared__ int lbase[ND];            // first local position of a digit
+    __shared__ int gbase[ND];            // global position of the digit's first pair of this workgroup
     __shared__ int wsum[4], wsum2[4];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint64_t lt = (1ull << lane) - 1ull;
-    for (int i = t; i < 4 * 256; i += 256) (&cnt[0][0])[i] = 0;
+    for (int i = t; i < 4 * ND; i += 256) (&cnt[0][0])[i] = 0;
     const int64_t base0 = (int64_t)blockIdx.x * WG_KEYS;
     const int64_t wbase = base0 + (int64_t)w * WAVE_KEYS;
     K key[ITEMS];
@@ -125,52 +130,59 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
         key[j] = (i < n) ? src[i] : (K)0;
         val[j] = (i < n) ? (iota ? (int32_t)i : vs[i]) : 0;
     }
-    // digit t: rows in front of this workgroup and the digit's total
-    int pre, total;
-    if (SELF_PREFIX) {
-        const int32_t* row = counts + (int64_t)t * nunits;
-        pre = 0;
-        total = 0;
-        for (int64_t u = 0; u < nunits; ++u) {
-            const int c = row[u];
-            total += c;
-            pre += (u < (int64_t)blockIdx.x) ? c : 0;
+    // digits h * 256 + t: rows in front of this workgroup and the digit's total
+    int pre[DH], total[DH];
+#pragma unroll
+    for (int h = 0; h < DH; ++h) {
+        const int d = h * 256 + t;
+        if (SELF_PREFIX) {
+            const int32_t* row = counts + (int64_t)d * nunits;
+            pre[h] = 0;
+            total[h] = 0;
+            for (int64_t u = 0; u < nunits; ++u) {
+                const int c = row[u];
+                total[h] += c;
+                pre[h] += (u < (int64_t)blockIdx.x) ? c : 0;
+            }
+        } else {
+            pre[h] = counts[(int64_t)d * nunits + blockIdx.x];
+            total[h] = totals[d];
         }
-    } else {
-        pre = counts[(int64_t)t * nunits + blockIdx.x];
-        total = totals[t];
     }
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j)
         if (wbase + j * 64 + lane < n) atomicAdd(&cnt[w][(unsigned)(key[j] >> shift) & dmask], 1);
-    const int inc = wave_inclusive_scan_i32(total, lane);
-    if (lane == 63) wsum[w] = inc;
     __syncthreads();
-    {   // digit t: its global base for this workgroup; its local base (exclusive scan of the workgroup's digit counts);
-        // then each wave's cursor into the local order (waves in input order)
-        int run = pre + inc - total;
-        for (int ww = 0; ww < w; ++ww) run += wsum[ww];
-        const int c0 = cnt[0][t], c1 = cnt[1][t], c2 = cnt[2][t], c3 = cnt[3][t];
+    // digit d: its global base for this workgroup (exclusive scan of the totals over the digits + the rows in front); its local
+    // base (exclusive scan of the workgroup's digit counts); then each wave's cursor into the local order (waves in input order)
+    int gcarry = 0, lcarry = 0;
+#pragma unroll
+    for (int h = 0; h < DH; ++h) {
+        const int d = h * 256 + t;
+        const int c0 = cnt[0][d], c1 = cnt[1][d], c2 = cnt[2][d], c3 = cnt[3][d];
         const int mine = c0 + c1 + c2 + c3;
+        const int inc = wave_inclusive_scan_i32(total[h], lane);
         const int linc = wave_inclusive_scan_i32(mine, lane);
-        if (lane == 63) wsum2[w] = linc;
+        if (lane == 63) { wsum[w] = inc; wsum2[w] = linc; }
         __syncthreads();
-        int lrun = linc - mine;
-        for (int ww = 0; ww < w; ++ww) lrun += wsum2[ww];
-        gbase[t] = run;
-        lbase[t] = lrun;
-        cnt[0][t] = lrun;
-        cnt[1][t] = lrun + c0;
-        cnt[2][t] = lrun + c0 + c1;
-        cnt[3][t] = lrun + c0 + c1 + c2;
+        int run = gcarry + pre[h] + inc - total[h], lrun = lcarry + linc - mine;
+        for (int ww = 0; ww < w; ++ww) { run += wsum[ww]; lrun += wsum2[ww]; }
+        gcarry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        lcarry += wsum2[0] + wsum2[1] + wsum2[2] + wsum2[3];
+        gbase[d] = run;
+        lbase[d] = lrun;
+        cnt[0][d] = lrun;
+        cnt[1][d] = lrun + c0;
+        cnt[2][d] = lrun + c0 + c1;
+        cnt[3][d] = lrun + c0 + c1 + c2;
+        __syncthreads();                                   // wsum / wsum2 are rewritten by the next half
     }
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool active = wbase + j * 64 + lane < n;
         const unsigned d = (unsigned)(key[j] >> shift) & dmask;
-        const uint64_t same = match_digit(d, active);
+        const uint64_t same = match_digit<DB>(d, active);
         const int below = __popcll(same & lt);
         int base = 0;
         if (active) {
@@ -193,25 +205,35 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const K* __restrict_
     }
 }
 
-int radix_sort_passes(int begin_bit, int end_bit) { return end_bit > begin_bit ? (end_bit - begin_bit + 7) / 8 : 0; }
+int radix_sort_passes(int begin_bit, int end_bit, int digit_bits) {
+    return end_bit > begin_bit ? (end_bit - begin_bit + digit_bits - 1) / digit_bits : 0;
+}
+
+// 27-bit execution-order keys: three 9-bit passes instead of four 8-bit ones — except in the mid shape, whose scatter sums its
+// digits' rows of unit counters itself (twice the rows per thread with 512 digits: 9.4 -> 14.6 us per pass, a loss)
+int radix_sort_order_digit_bits(int64_t n) {
+    const int64_t mid_units = (n + 256 * RS_MID_ITEMS - 1) / (256 * RS_MID_ITEMS);
+    return (n > RS_SMALL_N && mid_units <= RS_MID_MAX_UNITS) ? 8 : 9;
+}
 
 int64_t radix_sort_counter_bytes(int64_t n) {
     const int64_t mid = (n + 256 * RS_MID_ITEMS - 1) / (256 * RS_MID_ITEMS), big = (n + 256 * RS_BIG_ITEMS - 1) / (256 * RS_BIG_ITEMS);
     const int64_t nunits = mid <= RS_MID_MAX_UNITS ? mid : big;
-    return align256(256 * (nunits > 0 ? nunits : 1) * 4) + 1024;       // counters + 256 row totals
+    return align256(512 * (nunits > 0 ? nunits : 1) * 4) + 2048;       // counters + row totals, for up to 512 digits
 }
 
-template <class K>
+template <class K, int DB>
 static int radix_sort_pairs(K* ka, K* kb, int32_t* va, int32_t* vb, bool iota, int64_t n, int begin_bit, int end_bit, void* counters,
                             hipStream_t st) {
-    const int passes = radix_sort_passes(begin_bit, end_bit);
+    constexpr int ND = 1 << DB;
+    const int passes = radix_sort_passes(begin_bit, end_bit, DB);
     PCC_REQUIRE(passes >= 1 && end_bit <= (int)(8 * sizeof(K)) && begin_bit >= 0, "radix sort: bad bit range [%d, %d)", begin_bit, end_bit);
     PCC_REQUIRE(n < (1ll << 31), "radix sort: too many keys (%lld)", (long long)n);
     if (n <= 0) return PCC_OK;
     if (n <= RS_SMALL_N) {
         const int rounds = (int)(((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64);
-#define PCC_RS_SMALL(R)                                                                                                         \
-    hipLaunchKernelGGL((radix_sort_small_kernel<K, R>), dim3(1), dim3(RS_SMALL_THREADS), 0, st, ka, kb, va, vb, iota ? 1 : 0, (int)n, \
+#define PCC_RS_SMALL(R)                                                                                                             \
+    hipLaunchKernelGGL((radix_sort_small_kernel<K, R, DB>), dim3(1), dim3(RS_SMALL_THREADS), 0, st, ka, kb, va, vb, iota ? 1 : 0, (int)n, \
                        begin_bit, end_bit, passes)
         if (rounds <= 1) PCC_RS_SMALL(1);
         else if (rounds <= 2) PCC_RS_SMALL(2);
@@ -226,23 +248,23 @@ static int radix_sort_pairs(K* ka, K* kb, int32_t* va, int32_t* vb, bool iota, i
     const bool mid = mid_units <= RS_MID_MAX_UNITS;
     const int64_t nunits = mid ? mid_units : (n + 256 * RS_BIG_ITEMS - 1) / (256 * RS_BIG_ITEMS);
     int32_t* counts = reinterpret_cast<int32_t*>(counters);
-    int32_t* totals = counts + align256(256 * nunits * 4) / 4;
+    int32_t* totals = counts + align256((int64_t)ND * nunits * 4) / 4;
     K* src = ka;
     K* dst = kb;
     int32_t* vs = va;
     int32_t* vd = vb;
     for (int p = 0; p < passes; ++p) {
-        const int shift = begin_bit + 8 * p;
-        const unsigned dmask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
+        const int shift = begin_bit + DB * p;
+        const unsigned dmask = (end_bit - shift >= DB) ? (unsigned)(ND - 1) : ((1u << (end_bit - shift)) - 1u);
         const int io = (iota && p == 0) ? 1 : 0;
         if (mid) {
-            hipLaunchKernelGGL((radix_count_kernel<K, RS_MID_ITEMS>), dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
-            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_MID_ITEMS, true>), dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, io, n,
+            hipLaunchKernelGGL((radix_count_kernel<K, RS_MID_ITEMS, DB>), dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
+            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_MID_ITEMS, true, DB>), dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, io, n,
                                shift, dmask, nunits, counts, totals);
         } else {
-            hipLaunchKernelGGL((radix_count_kernel<K, RS_BIG_ITEMS>), dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
-            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, st, counts, nunits, totals);
-            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_BIG_ITEMS, false>), dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, io, n,
+            hipLaunchKernelGGL((radix_count_kernel<K, RS_BIG_ITEMS, DB>), dim3((unsigned)nunits), dim3(256), 0, st, src, n, shift, dmask, nunits, counts);
+            hipLaunchKernelGGL(radix_rowscan_kernel, dim3(ND), dim3(256), 0, st, counts, nunits, totals);
+            hipLaunchKernelGGL((radix_scatter_kernel<K, RS_BIG_ITEMS, false, DB>), dim3((unsigned)nunits), dim3(256), 0, st, src, dst, vs, vd, io, n,
                                shift, dmask, nunits, counts, totals);
         }
         K* tk = src; src = dst; dst = tk;
@@ -253,13 +275,14 @@ static int radix_sort_pairs(K* ka, K* kb, int32_t* va, int32_t* vb, bool iota, i
 }
 
 int radix_sort_pairs_u32(uint32_t* keys_a, uint32_t* keys_b, int32_t* vals_a, int32_t* vals_b, bool vals_are_iota, int64_t n, int begin_bit,
-                         int end_bit, void* counters, hipStream_t st) {
-    return radix_sort_pairs<uint32_t>(keys_a, keys_b, vals_a, vals_b, vals_are_iota, n, begin_bit, end_bit, counters, st);
+                         int end_bit, void* counters, hipStream_t st, int digit_bits) {
+    if (digit_bits == 9) return radix_sort_pairs<uint32_t, 9>(keys_a, keys_b, vals_a, vals_b, vals_are_iota, n, begin_bit, end_bit, counters, st);
+    return radix_sort_pairs<uint32_t, 8>(keys_a, keys_b, vals_a, vals_b, vals_are_iota, n, begin_bit, end_bit, counters, st);
 }
 
 int radix_sort_pairs_u64(uint64_t* keys_a, uint64_t* keys_b, int32_t* vals_a, int32_t* vals_b, bool vals_are_iota, int64_t n, int begin_bit,
                          int end_bit, void* counters, hipStream_t st) {
-    return radix_sort_pairs<uint64_t>(keys_a, keys_b, vals_a, vals_b, vals_are_iota, n, begin_bit, end_bit, counters, st);
+    return radix_sort_pairs<uint64_t, 8>(keys_a, keys_b, vals_a, vals_b, vals_are_iota, n, begin_bit, end_bit, counters, st);
 }
 
 }  // namespace pcc

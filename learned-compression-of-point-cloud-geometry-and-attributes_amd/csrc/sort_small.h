@@ -11,11 +11,12 @@ constexpr int RS_SMALL_WAVES = RS_SMALL_THREADS / 64;
 constexpr int RS_SMALL_ROUNDS = 16;                                       // rounds of 64 keys per wave, held in registers
 constexpr int64_t RS_SMALL_N = (int64_t)RS_SMALL_WAVES * 64 * RS_SMALL_ROUNDS;   // 16384
 
-// lanes of this wave that are active and hold the same 8-bit digit as the calling lane
+// lanes of this wave that are active and hold the same DB-bit digit as the calling lane
+template <int DB = 8>
 __device__ __forceinline__ uint64_t match_digit(unsigned d, bool active) {
     uint64_t same = __ballot(active);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < DB; ++b) {
         const bool bit = (d >> b) & 1u;
         const uint64_t bal = __ballot(active && bit);
         same &= bit ? bal : ~bal;
@@ -33,13 +34,16 @@ __device__ __forceinline__ int wave_inclusive_scan_i32(int v, int lane) {
 }
 
 // ROUNDS: rounds of 64 keys per wave (compile-time: the sweeps are unrolled over the register-resident keys; a 1.2 k-row
-// set runs the 1-round instance instead of 16 mostly predicated-off rounds)
-template <class K, int ROUNDS>
+// set runs the 1-round instance instead of 16 mostly predicated-off rounds).  DB: digit bits — 8, or 9 for the 27-bit
+// execution-order keys (three passes instead of four: 32 KB of counters instead of 16).
+template <class K, int ROUNDS, int DB = 8>
 __device__ __forceinline__ void radix_sort_small_body(K* ka, K* kb, int32_t* va, int32_t* vb, int iota, int n, int begin_bit, int end_bit,
                                                       int passes) {
-    __shared__ int cnt[RS_SMALL_WAVES][256];
-    __shared__ int tot[256];
-    __shared__ int wsum[4];
+    constexpr int ND = 1 << DB;
+    static_assert(ND <= RS_SMALL_THREADS, "one thread per digit");
+    __shared__ int cnt[RS_SMALL_WAVES][ND];
+    __shared__ int tot[ND];
+    __shared__ int wsum[ND / 64];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int chunk = ((n + RS_SMALL_WAVES - 1) / RS_SMALL_WAVES + 63) / 64 * 64;      // <= 64 * ROUNDS
     const int lo = w * chunk < n ? w * chunk : n;
@@ -50,8 +54,8 @@ __device__ __forceinline__ void radix_sort_small_body(K* ka, K* kb, int32_t* va,
     int32_t* vs = va;
     int32_t* vd = vb;
     for (int p = 0; p < passes; ++p) {
-        const int shift = begin_bit + 8 * p;
-        const unsigned dmask = (end_bit - shift >= 8) ? 255u : ((1u << (end_bit - shift)) - 1u);
+        const int shift = begin_bit + DB * p;
+        const unsigned dmask = (end_bit - shift >= DB) ? (unsigned)(ND - 1) : ((1u << (end_bit - shift)) - 1u);
         // the wave's chunk in registers: one batch of loads per pass
         K key[ROUNDS];
         int32_t val[ROUNDS];
@@ -61,7 +65,7 @@ __device__ __forceinline__ void radix_sort_small_body(K* ka, K* kb, int32_t* va,
             key[j] = (i < hi) ? src[i] : (K)0;
             val[j] = (i < hi) ? ((iota && p == 0) ? i : vs[i]) : 0;
         }
-        for (int i = t; i < RS_SMALL_WAVES * 256; i += RS_SMALL_THREADS) (&cnt[0][0])[i] = 0;
+        for (int i = t; i < RS_SMALL_WAVES * ND; i += RS_SMALL_THREADS) (&cnt[0][0])[i] = 0;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ROUNDS; ++j)
@@ -69,7 +73,7 @@ __device__ __forceinline__ void radix_sort_small_body(K* ka, K* kb, int32_t* va,
         __syncthreads();
         // digit t: chunk bases (exclusive over the waves, input order) and the digit's total
         int v = 0;
-        if (t < 256) {
+        if (t < ND) {
             int run = 0;
 #pragma unroll
             for (int ww = 0; ww < RS_SMALL_WAVES; ++ww) {
@@ -80,9 +84,9 @@ __device__ __forceinline__ void radix_sort_small_body(K* ka, K* kb, int32_t* va,
             v = run;
         }
         const int inc = wave_inclusive_scan_i32(v, lane);
-        if (lane == 63 && w < 4) wsum[w] = inc;
+        if (lane == 63 && w < ND / 64) wsum[w] = inc;
         __syncthreads();
-        if (t < 256) {
+        if (t < ND) {
             int base = 0;
             for (int ww = 0; ww < w; ++ww) base += wsum[ww];
             tot[t] = base + inc - v;
@@ -93,7 +97,7 @@ __device__ __forceinline__ void radix_sort_small_body(K* ka, K* kb, int32_t* va,
             const int i = lo + j * 64 + lane;
             const bool active = i < hi;
             const unsigned d = (unsigned)(key[j] >> shift) & dmask;
-            const uint64_t same = match_digit(d, active);
+            const uint64_t same = match_digit<DB>(d, active);
             const int below = __popcll(same & lt);
             int base = 0;
             if (active) {
