@@ -1045,6 +1045,16 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sd = {n_: t.detach().cpu() for n_, t in model.state_dict().items()}
         out["cpu_baseline"] = cpu_baseline(model, sd, args.cpu_sample, dev, args.cpu_order)
+        if args.cpu_order == "kernel":
+            # the slower CPU implementation SURVEY.md §8d names (torch-CPU sgemm per offset + index_add_) is not re-run by the default
+            # command (2.5 minutes); its newest committed measurement (`python bench.py --cpu-order blas`) rides along, labelled
+            other = latest_profile("cpu_baseline_blas_order")
+            if other and other.get("cpu_baseline"):
+                ob = other["cpu_baseline"]
+                out["cpu_baseline"]["blas_order_oracle"] = {
+                    "value": ob["value"], "unit": ob["unit"], "cores": ob["cores"], "cpu_model": ob.get("cpu_model"), "sample": ob["sample"],
+                    "parity_abs_diff": ob.get("parity", {}).get("abs_diff"), "decoded_voxels_differing": ob.get("parity", {}).get("decoded_voxels_differing"),
+                    "replayed_from": {"file": other["_file"], "commit": other.get("commit"), "note": "not re-measured in this run"}}
     elif rank == 0:
         # N > 1 (and --no-cpu-baseline): the baseline is measured on rank 0 at N = 1 only (minutes of host work); carry the newest
         # committed N = 1 record along, labelled as replayed, so that a scaling line is as complete as the N = 1 line
