@@ -90,7 +90,9 @@ class ColorModel(nn.Module):
             nbatch = int(bcol.max().item()) + 1
         coords = torch.cat([bcol, x[:, :3].to(torch.int32)], dim=1)
         feats = torch.cat([torch.ones((N, 1), device=dev, dtype=torch.float32), x[:, 3:6].float()], dim=1)
-        inp = SparseTensor(feats, coordinate_map=CoordMap(coords.contiguous(), 1, nbatch=nbatch))
+        in_map = CoordMap(coords.contiguous(), 1, nbatch=nbatch)
+        in_map.count_duplicates()
+        inp = SparseTensor(feats, coordinate_map=in_map)
         if Q.map._nbatch is None:
             Q.map._nbatch = nbatch
         y, Q8, k = self.g_a(inp, Q)
@@ -104,6 +106,12 @@ class ColorModel(nn.Module):
             _, Q_strings, Q_shape = self.entropy_model_map.compress(Q8)
             strings, shape = [y_strings, Q_strings], [y_shape, Q_shape]
         coordinates = y.C
+        # (the range coder has waited for the stream: this read costs a few microseconds)
+        dups = in_map.duplicates()
+        if dups:
+            raise ValueError(f"compress: {dups} of the {N} points repeat the voxel coordinates of an earlier point.  The reference's "
+                             "ME.SparseTensor (model/model.py:121) would keep an unspecified one of each group; drop them first "
+                             "(e.g. torch.unique on the coordinates, or pcc_amd.metrics._drop_duplicated_points: first occurrence wins)")
         if path:
             self.save_bitstream(path=path, points=coordinates, strings=strings, shape=shape, k=k)
             return None

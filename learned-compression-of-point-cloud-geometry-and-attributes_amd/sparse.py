@@ -182,6 +182,7 @@ class CoordMap:
         self._table = table          # (keys uint64-as-int64, vals int32, cap)
         self._nbatch = nbatch
         self._cache = {}
+        self._dup_word = None        # count_duplicates(): device int32 the table build adds the duplicate rows to
 
     # -- basic properties ------------------------------------------------------------------
     @property
@@ -205,10 +206,20 @@ class CoordMap:
             keys = torch.empty(cap, dtype=torch.int64, device=self.device)
             vals = torch.empty(cap, dtype=torch.int32, device=self.device)
             ev = _cp_begin()
-            check(L.pcc_hash_build(ptr(self.coords), self.n, ptr(keys), ptr(vals), cap, self.stride, None, _lib.stream()))
+            check(L.pcc_hash_build(ptr(self.coords), self.n, ptr(keys), ptr(vals), cap, self.stride, ptr(self._dup_word), _lib.stream()))
             _cp_end(ev, "hash_build", self.n, 28 * self.n + 12 * cap)      # table cleared (12 B / slot), coordinates read, key + value written
             self._table = (keys, vals, cap)
         return self._table
+
+    def count_duplicates(self):
+        """Ask the table build (which must not have happened yet) to count rows whose coordinates an earlier row already holds; read
+        the count with duplicates() once the stream has been waited for anyway.  For coordinate lists that come from outside
+        (ColorModel.compress): ME's SparseTensor constructor would have dropped such rows (an unspecified one of each group)."""
+        assert self._table is None
+        self._dup_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def duplicates(self):
+        return 0 if self._dup_word is None or self._table is None else int(self._dup_word.item())
 
     def lookup(self, query):
         """Row index of every query coordinate (int32 [M,4]) or -1."""

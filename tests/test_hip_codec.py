@@ -315,6 +315,19 @@ def test_grid_corners_and_empty_input(pcc, model, oracle_codec):
         model.compress(torch.zeros((0, 6), device=DEV), Q)
 
 
+def test_duplicate_input_points_are_an_error(pcc, model):
+    """two points in one voxel: ME's SparseTensor constructor (model/model.py:121) would keep an unspecified one of them, so there is
+    no result to reproduce — compress says so instead of coding a cloud with an orphan row; the de-duplicated cloud codes as usual"""
+    pts = pcc.synthetic.sphere_shell(**pcc.synthetic.CONFIG1)
+    dup = np.concatenate([pts, pts[100:137] * np.array([1, 1, 1, 0.5, 0.5, 0.5], np.float32)])
+    qc, qf = pcc.synthetic.uniform_qmap(dup[:, :3], 0.5, 0.5)
+    Q = pcc.SparseTensor(coordinates=torch.from_numpy(qc[:pts.shape[0]]).to(DEV), features=torch.from_numpy(qf[:pts.shape[0]]).to(DEV), device=DEV)
+    with pytest.raises(ValueError, match="37 of the 4941 points repeat"):
+        model.compress(torch.from_numpy(dup).to(DEV), Q)
+    strings, shape, k, coords = model.compress(torch.from_numpy(pts).to(DEV), Q)          # the same model goes on working
+    assert k[2] == [pts.shape[0]]
+
+
 def test_full_size_frame_properties(pcc, model):
     """BASELINE config 2 (N = 850,824), size-independent properties instead of an oracle run:
     determinism (same bytes twice, same reconstruction twice), header facts, k consistency,
