@@ -85,3 +85,17 @@ def test_n_gt_1_line_carries_the_committed_cpu_baseline():
     import bench
     prev = bench.latest_profile("bench_config2")
     assert prev is not None and prev.get("cpu_baseline") and prev["cpu_baseline"]["value"] > 0 and prev["cpu_baseline"]["cores"] >= 1
+
+
+def test_default_line_carries_the_committed_blas_order_baseline():
+    """the default cpu_baseline is the kernel-order oracle (the faster CPU implementation); the BLAS-order oracle SURVEY §8d names rides
+    along replayed from its committed record, which must exist, be slower, and hold its tolerance-class parity"""
+    import bench
+    blas = bench.latest_profile("cpu_baseline_blas_order")
+    assert blas is not None and blas["cpu_baseline"]["parity"]["oracle_summation_order"] == "blas"
+    d = blas["cpu_baseline"]["parity"]["abs_diff"]
+    assert d["bpp"] <= 1e-3 and d["d1_psnr_db"] <= 1e-3 and d["y_psnr_db"] <= 1e-3
+    main = bench.latest_profile("bench_config2")["cpu_baseline"]
+    assert main["parity"]["oracle_summation_order"] == "kernel" and main["parity"]["streams_byte_equal"] is True
+    assert main["parity"]["decoded_voxels_differing"] == 0 and main["parity"]["colours_differing"] == 0
+    assert main["value"] > 2 * blas["cpu_baseline"]["value"]
