@@ -216,7 +216,7 @@ class CoordMap:
         the count with duplicates() once the stream has been waited for anyway.  For coordinate lists that come from outside
         (ColorModel.compress): ME's SparseTensor constructor would have dropped such rows (an unspecified one of each group)."""
         assert self._table is None
-        self._dup_word = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._dup_word = torch.empty(1, dtype=torch.int32, device=self.device)       # (pcc_hash_build clears it)
 
     def duplicates(self):
         return 0 if self._dup_word is None or self._table is None else int(self._dup_word.item())
