@@ -14,7 +14,7 @@
  *     allocates device memory.  `stream` is a hipStream_t passed as void*.
  *   - every function returns 0 on success or a negative PCC_ERR_* code; the message is
  *     available from pcc_last_error() (thread-local).  No exceptions cross the ABI.
- *   - coordinates: int32 [N,4] rows (batch, x, y, z), |x|,|y|,|z| < 32767, batch < 32767.
+ *   - coordinates: int32 [N,4] rows (batch, x, y, z), |x|,|y|,|z| <= PCC_COORD_LIMIT, batch <= PCC_BATCH_LIMIT.
  *   - features: fp32 row-major [N, C].  Neighbour tables: int32 [N_out, K], -1 = absent.
  *   - hash table = (keys uint64[cap], vals int32[cap], tensor_stride), cap a power of two from
  *     pcc_hash_capacity(); a table is immutable once built and may be read concurrently.
@@ -55,14 +55,14 @@ int pcc_device_name(int dev, char* out, int out_len);
  * ------------------------------------------------------------------------------------- */
 int64_t pcc_hash_capacity(int64_t n);
 
-/* Coordinate range.  A voxel key has 16 bits per field: coordinates must satisfy |c| <= PCC_COORD_LIMIT and batch
- * indices 0 <= b <= PCC_BATCH_LIMIT (the reference's radix-1e5 keys, model/blocks.py:118 and utils.py:170, take larger
- * grids; 10- to 14-bit voxelisations fit).  A set with a coordinate outside the range is never hashed with an aliased
- * key: pcc_stride_map / pcc_children check the source rows and every generated coordinate and report
- * *out_count = PCC_COUNT_ERR_RANGE instead of a row count — the error reaches the host with the one value it reads
- * anyway, at no extra synchronisation (the Python side raises ValueError). */
-#define PCC_COORD_LIMIT 32000
-#define PCC_BATCH_LIMIT 32766
+/* Coordinate range.  A voxel key has 10 bits of batch index and 18 bits per coordinate: coordinates must satisfy
+ * |c| <= PCC_COORD_LIMIT and batch indices 0 <= b <= PCC_BATCH_LIMIT — the reference's radix-1e5 keys (model/blocks.py:118 and
+ * utils.py:170: coordinates 0 .. 99,999) fit, with the same span on the negative side.  A set with a coordinate outside the
+ * range is never hashed with an aliased key: pcc_stride_map / pcc_children check the source rows and every generated
+ * coordinate and report *out_count = PCC_COUNT_ERR_RANGE instead of a row count — the error reaches the host with the one
+ * value it reads anyway, at no extra synchronisation (the Python side raises ValueError). */
+#define PCC_COORD_LIMIT 130000
+#define PCC_BATCH_LIMIT 1022
 #define PCC_COUNT_ERR_RANGE (-2)
 
 /* Insert rows 0..n-1; table value = row index.  Duplicate coordinates keep the smallest

@@ -37,17 +37,20 @@ static inline unsigned blocks_for(int64_t n, int per_block, unsigned cap = 0x7ff
     return (unsigned)b;
 }
 
-// ---- voxel key: (b << 48) | (x+2^15) << 32 | (y+2^15) << 16 | (z+2^15).
-// Ascending key order == lexicographic (b, x, y, z): the reference's canonical order
-// (utils.py:170-171).  16 bits per field: valid for |coord| <= COORD_LIMIT and 0 <= b <= BATCH_LIMIT — the margin below
-// 2^15 keeps every neighbour probe (coordinate +- one step of a tensor stride <= 512) inside the field, so a key never
-// wraps onto another voxel's.  The reference's radix-1e5 keys (model/blocks.py:118, utils.py:170) take larger grids;
-// here a coordinate outside the range is an ERROR reported with the row count of the next coordinate-set
-// construction (coords.hip: unique_insert -> COUNT_ERR_RANGE), never an aliased key.
+// ---- voxel key: (b << 54) | (x+2^17) << 36 | (y+2^17) << 18 | (z+2^17): 10 bits of batch index, 18 bits per coordinate.
+// Ascending key order == lexicographic (b, x, y, z): the reference's canonical order (utils.py:170-171).  Valid for
+// |coord| <= COORD_LIMIT and 0 <= b <= BATCH_LIMIT — the margin below 2^17 keeps every neighbour probe (coordinate +- one step
+// of a tensor stride <= 512) inside the field, so a key never wraps onto another voxel's.  The range covers the reference's
+// radix-1e5 keys (model/blocks.py:118, utils.py:170: coordinates 0 .. 99,999) and as much again on the negative side (rounds
+// 1-3 had 16-bit fields: |coord| <= 32,000); a coordinate outside it is an ERROR reported with the row count of the next
+// coordinate-set construction (coords.hip: unique_insert -> COUNT_ERR_RANGE), never an aliased key.
 constexpr uint64_t KEY_EMPTY = 0xFFFFFFFFFFFFFFFFull;
-constexpr int COORD_BIAS = 1 << 15;
-constexpr int COORD_LIMIT = 32000;
-constexpr int BATCH_LIMIT = 32766;
+constexpr int KEY_FIELD_BITS = 18;
+constexpr uint32_t KEY_FIELD_MASK = (1u << KEY_FIELD_BITS) - 1u;
+constexpr int KEY_Y_SHIFT = KEY_FIELD_BITS, KEY_X_SHIFT = 2 * KEY_FIELD_BITS, KEY_B_SHIFT = 3 * KEY_FIELD_BITS;
+constexpr int COORD_BIAS = 1 << (KEY_FIELD_BITS - 1);      // a multiple of every power-of-two grid pitch (kernel_map27's on-grid test)
+constexpr int COORD_LIMIT = 130000;
+constexpr int BATCH_LIMIT = 1022;
 constexpr int64_t COUNT_ERR_RANGE = -2;      // written instead of a row count (PCC_COUNT_ERR_RANGE in pcc_hip.h)
 
 __host__ __device__ __forceinline__ bool coord_in_range(int b, int x, int y, int z) {
@@ -56,9 +59,14 @@ __host__ __device__ __forceinline__ bool coord_in_range(int b, int x, int y, int
 }
 
 __host__ __device__ __forceinline__ uint64_t pack_key(int b, int x, int y, int z) {
-    return ((uint64_t)(uint16_t)b << 48) | ((uint64_t)(uint16_t)(x + COORD_BIAS) << 32) |
-           ((uint64_t)(uint16_t)(y + COORD_BIAS) << 16) | (uint64_t)(uint16_t)(z + COORD_BIAS);
+    return ((uint64_t)((uint32_t)b & 0x3FFu) << KEY_B_SHIFT) | ((uint64_t)((uint32_t)(x + COORD_BIAS) & KEY_FIELD_MASK) << KEY_X_SHIFT) |
+           ((uint64_t)((uint32_t)(y + COORD_BIAS) & KEY_FIELD_MASK) << KEY_Y_SHIFT) | (uint64_t)((uint32_t)(z + COORD_BIAS) & KEY_FIELD_MASK);
 }
+
+// the three biased coordinate fields of a key
+__host__ __device__ __forceinline__ uint32_t key_z(uint64_t key) { return (uint32_t)key & KEY_FIELD_MASK; }
+__host__ __device__ __forceinline__ uint32_t key_y(uint64_t key) { return (uint32_t)(key >> KEY_Y_SHIFT) & KEY_FIELD_MASK; }
+__host__ __device__ __forceinline__ uint32_t key_x(uint64_t key) { return (uint32_t)(key >> KEY_X_SHIFT) & KEY_FIELD_MASK; }
 
 __device__ __forceinline__ uint64_t hash_key(uint64_t k) {
     // splitmix64 finaliser
@@ -75,10 +83,11 @@ __device__ __forceinline__ uint64_t hash_key(uint64_t k) {
 // by 8 slots — each of the 8 lanes is an ordinary linear-probing table over runs, so dense runs do not lengthen
 // the unsuccessful probes the way slot-by-slot probing through a spatial block does.
 __device__ __forceinline__ uint64_t table_slot0(uint64_t key, uint64_t mask, int shift) {
-    const uint32_t z = (uint32_t)key & 0xFFFFu;
-    // 32-bit mix of the run (b, x | y, z-run): the probe kernels are bound by VALU issue as much as by memory, and a
-    // 64-bit splitmix is ~55 issue slots on CDNA (four quarter-rate 32-bit multiplies per 64-bit product) against ~25 here
-    const uint32_t lo = ((uint32_t)key & 0xFFFF0000u) | (z >> (shift + 3)), hi = (uint32_t)(key >> 32);
+    const uint32_t z = key_z(key);
+    // 32-bit mix of the run (the key without the 3 + shift low bits of z: bits of the z-run, y and x in `lo`, the rest of y, x
+    // and b in `hi`): the probe kernels are bound by VALU issue as much as by memory, and a 64-bit splitmix is ~55 issue slots
+    // on CDNA (four quarter-rate 32-bit multiplies per 64-bit product) against ~25 here
+    const uint32_t lo = (uint32_t)(key >> (shift + 3)), hi = (uint32_t)(key >> 32);
     uint32_t h = lo * 0x9E3779B1u + hi * 0x85EBCA77u;
     h ^= h >> 15; h *= 0x2C1B3C6Du;
     h ^= h >> 12; h *= 0x297A2D39u;

@@ -477,7 +477,7 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
                                                            int step, int parent_pitch, int32_t* __restrict__ nbr,
                                                            uint32_t* __restrict__ row_mask,
                                                            unsigned long long* __restrict__ pair_count) {
-    // A neighbour's key is the row's key plus a constant: every field of a voxel key stays inside its 16 bits under a step of
+    // A neighbour's key is the row's key plus a constant: every field of a voxel key stays inside its 18 bits under a step of
     // one stride (COORD_LIMIT's margin, common.h), so the 64-bit sum of the row's key and the offset's packed delta IS
     // pack_key(b, x + dx step, y + dy step, z + dz step) — one add per probe instead of three coordinate adds and a pack.
     __shared__ uint64_t rowkey[64];
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     if (threadIdx.x >= 64 && threadIdx.x < 64 + 27) {
         const int k = threadIdx.x - 64;
         const int64_t dx = (int64_t)(k % 3 - 1) * step, dy = (int64_t)((k / 3) % 3 - 1) * step, dz = (int64_t)(k / 9 - 1) * step;
-        dkey[k] = (uint64_t)(dx * (1ll << 32) + dy * (1ll << 16) + dz);
+        dkey[k] = (uint64_t)(dx * (1ll << KEY_X_SHIFT) + dy * (1ll << KEY_Y_SHIFT) + dz);
     }
     if (threadIdx.x == 0) hits_s = 0u;
     __syncthreads();
@@ -507,12 +507,12 @@ __global__ __launch_bounds__(256) void kernel_map27_kernel(const int32_t* __rest
     // transposed maps: the parent must lie on the grid of pitch 2 step; COORD_BIAS is a multiple of every power-of-two pitch,
     // so the test reads the biased fields of the key directly
     auto off_grid_key = [&](uint64_t key) {
-        const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
         if (POW2) {
+            // (pitches are <= 2^10: the low bits of the three fields are read straight off the shifted key)
             const uint32_t m = (uint32_t)(parent_pitch - 1);
-            return (((lo | (lo >> 16) | hi) & m) != 0u);
+            return ((((uint32_t)key | (uint32_t)(key >> KEY_Y_SHIFT) | (uint32_t)(key >> KEY_X_SHIFT)) & m) != 0u);
         }
-        const int z = (int)(lo & 0xFFFFu) - COORD_BIAS, y = (int)(lo >> 16) - COORD_BIAS, x = (int)(hi & 0xFFFFu) - COORD_BIAS;
+        const int z = (int)key_z(key) - COORD_BIAS, y = (int)key_y(key) - COORD_BIAS, x = (int)key_x(key) - COORD_BIAS;
         return (x % parent_pitch) != 0 || (y % parent_pitch) != 0 || (z % parent_pitch) != 0;
     };
     // Two phases (round 4; profiles/r04_kernel_map_counters.txt).  The one-probe-at-a-time loop this replaces left every lane with

@@ -644,7 +644,7 @@ int64_t pcc_topk_state_elems(int32_t nbatch) { return (int64_t)nbatch * TK_STRID
 
 int pcc_topk_mask(const float* logits, int32_t ld, const int32_t* coords, int64_t n, int32_t nbatch, const int32_t* k,
                   uint8_t* mask, int32_t* state, void* stream) {
-    PCC_REQUIRE(nbatch >= 1 && nbatch < 32767, "pcc_topk_mask: bad nbatch %d", nbatch);
+    PCC_REQUIRE(nbatch >= 1 && nbatch <= BATCH_LIMIT + 1, "pcc_topk_mask: bad nbatch %d", nbatch);
     PCC_REQUIRE(ld >= 1, "pcc_topk_mask: bad leading dimension");
     hipStream_t st = as_stream(stream);
     if (small_path_enabled(1) && nbatch == 1 && n > 0 && n <= TK_SMALL_N) {      // PCC_TOPK_SMALL=0: never (A/B)

@@ -105,7 +105,7 @@ def set_small_paths(mask):
 
 
 class CoordinateRangeError(ValueError):
-    """a coordinate outside the voxel key's range (|c| <= 32000, 0 <= batch index <= 32766: include/pcc_hip.h)"""
+    """a coordinate outside the voxel key's range (|c| <= 130000, 0 <= batch index <= 1022: include/pcc_hip.h)"""
 
 
 COUNT_ARMED, COUNT_ERR_RANGE = -1, -2            # PCC_COUNT_ERR_RANGE of include/pcc_hip.h
@@ -128,9 +128,9 @@ def _read_count(buf, device):
             time.sleep(0)
     n = int(arr[0])
     if n == COUNT_ERR_RANGE:
-        raise CoordinateRangeError("libpcc_hip: a voxel coordinate is outside the supported range (|c| <= 32000, batch index "
-                                   "<= 32766): the 16-bit fields of the voxel key would alias — re-voxelise to <= 14 bits or "
-                                   "translate the cloud towards the origin")
+        raise CoordinateRangeError("libpcc_hip: a voxel coordinate is outside the supported range (|c| <= 130000, batch index "
+                                   "<= 1022): the 18-bit fields of the voxel key would alias — translate the cloud towards the "
+                                   "origin or re-voxelise it")
     if n < 0:
         raise RuntimeError("libpcc_hip: the row count was never written (kernel failure?)")
     return n

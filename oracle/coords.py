@@ -18,30 +18,34 @@ Test infrastructure only — see oracle/__init__.py.
 """
 import numpy as np
 
-_OFF = 1 << 15  # coordinates must lie in (-32768, 32767)
+_BITS = 18
+_OFF = 1 << (_BITS - 1)  # coordinates must lie in (-2^17, 2^17 - 1); 10 bits of batch index
 
 
 def pack(coords):
     """int64 key whose ascending order is lexicographic (b, x, y, z).
 
     Same ordering as the reference's radix-1e5 key (utils.py:170-171,199-200)
-    for coordinates in (-5e4, 5e4); here the radix is 2^16 with a +2^15 bias.
+    for its coordinates (0 .. 99,999); here the radix is 2^18 with a +2^17 bias (the product's layout, csrc/common.h).
     """
     c = np.asarray(coords).astype(np.int64)
     assert c.ndim == 2 and c.shape[1] == 4
     if c.size:
-        assert c[:, 0].min() >= 0 and c[:, 0].max() < _OFF, "batch index out of range"
+        assert c[:, 0].min() >= 0 and c[:, 0].max() < 1023, "batch index out of range"
         assert c[:, 1:].min() > -_OFF and c[:, 1:].max() < _OFF - 1, "coordinate out of range"
-    return (c[:, 0] << 48) | ((c[:, 1] + _OFF) << 32) | ((c[:, 2] + _OFF) << 16) | (c[:, 3] + _OFF)
+    u = np.uint64
+    return ((c[:, 0].astype(u) << u(3 * _BITS)) | ((c[:, 1] + _OFF).astype(u) << u(2 * _BITS))
+            | ((c[:, 2] + _OFF).astype(u) << u(_BITS)) | (c[:, 3] + _OFF).astype(u))          # uint64: batch 512+ sets bit 63
 
 
 def unpack(keys):
-    k = np.asarray(keys, dtype=np.int64)
+    k = np.asarray(keys, dtype=np.uint64)
+    m = np.uint64((1 << _BITS) - 1)
     out = np.empty((k.shape[0], 4), dtype=np.int32)
-    out[:, 0] = (k >> 48) & 0xFFFF
-    out[:, 1] = ((k >> 32) & 0xFFFF) - _OFF
-    out[:, 2] = ((k >> 16) & 0xFFFF) - _OFF
-    out[:, 3] = (k & 0xFFFF) - _OFF
+    out[:, 0] = (k >> np.uint64(3 * _BITS)).astype(np.int64)
+    out[:, 1] = ((k >> np.uint64(2 * _BITS)) & m).astype(np.int64) - _OFF
+    out[:, 2] = ((k >> np.uint64(_BITS)) & m).astype(np.int64) - _OFF
+    out[:, 3] = (k & m).astype(np.int64) - _OFF
     return out
 
 

@@ -315,6 +315,31 @@ def test_grid_corners_and_empty_input(pcc, model, oracle_codec):
         model.compress(torch.zeros((0, 6), device=DEV), Q)
 
 
+def test_translated_clouds_code_to_the_same_bytes_up_to_the_reference_key_range(pcc, model):
+    """a translation by multiples of 32 (the coarsest lattice of the path) moves every coordinate set rigidly: kernel maps, canonical
+    order and top-k tie-breaks are those of the untranslated cloud, so the streams must be byte-equal and the reconstruction the same
+    cloud moved — at the far end of the reference's radix-1e5 key range (model/blocks.py:118: coordinates up to 99,999, beyond the
+    +-32,000 of rounds 1-3), and as far on the negative side"""
+    pts = pcc.synthetic.sphere_shell(grid=64, radius=27.0, half_width=0.6)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.4, 0.7)
+    base = _compress(pcc, model, pts, qc, qf)
+    rec0 = model.decompress(coordinates=base[3], strings=base[0], shape=base[1], k=base[2]).cpu().numpy()
+    for off in ((99904, 65536, 98304), (-98304, 32, -129888 + 32 * 1)):
+        off = np.array(off, np.float32)
+        assert (off % 32 == 0).all() and np.abs(off).max() + 64 <= 130000
+        moved = pts.copy()
+        moved[:, :3] += off
+        mq = qc.copy()
+        mq[:, 1:] += off
+        strings, shape, k, coords = _compress(pcc, model, moved, mq, qf)
+        assert (shape, k) == (base[1], base[2])
+        assert strings[0][0] == base[0][0][0] and strings[1][0] == base[0][1][0], off
+        rec = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k).cpu().numpy()
+        a = rec[np.lexsort((rec[:, 2], rec[:, 1], rec[:, 0]))]
+        b = rec0[np.lexsort((rec0[:, 2], rec0[:, 1], rec0[:, 0]))]
+        assert np.array_equal(a[:, :3], b[:, :3] + off) and np.array_equal(a[:, 3:], b[:, 3:]), off
+
+
 def test_duplicate_input_points_are_an_error(pcc, model):
     """two points in one voxel: ME's SparseTensor constructor (model/model.py:121) would keep an unspecified one of them, so there is
     no result to reproduce — compress says so instead of coding a cloud with an orphan row; the de-duplicated cloud codes as usual"""

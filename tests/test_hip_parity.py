@@ -87,15 +87,15 @@ def test_stride_map(pcc, ts):
     assert (d.lookup(d.coords).cpu().numpy() == np.arange(got.shape[0])).all()
 
 
-@pytest.mark.parametrize("bad", [(0, 1 << 15, 5, 5), (0, 5, -(1 << 15), 5), (0, 7, 7, 32001), (32767, 1, 2, 3), (0, 65536 + 3, 4, 5)])
+@pytest.mark.parametrize("bad", [(0, 1 << 17, 5, 5), (0, 5, -(1 << 17), 5), (0, 7, 7, 130001), (1023, 1, 2, 3), (0, (1 << 18) + 3, 4, 5)])
 def test_coordinates_outside_the_key_range_are_an_error_not_an_alias(pcc, model_for_range, bad):
-    """16 bits per key field (csrc/common.h): a 2^15 / 16-bit-voxelised coordinate would wrap onto another voxel's key.
+    """18 bits per coordinate field, 10 for the batch index (csrc/common.h): a coordinate of 2^17 would wrap onto another voxel's key.
     The next coordinate-set construction reports it with the row count (PCC_COUNT_ERR_RANGE) and the Python side raises
     ValueError — from the operator, from ColorModel.compress and from decompress; the limit itself is accepted."""
     c = shell_coords(pcc, grid=24, radius=9.0)
-    ok = np.concatenate([c, np.array([[0, 32000, -32000, 32000], [32766, 0, 0, 0]], np.int32)])
+    ok = np.concatenate([c, np.array([[0, 130000, -130000, 130000], [1022, 0, 0, 0], [0, 99999, 99999, 99999]], np.int32)])
     assert pcc.CoordMap(dev(ok), 1).down().n > 0                                  # both limits are inside
-    assert pcc.CoordMap(dev(np.array([[0, 31992, -31992, 0], [1, 8, 8, 8]], np.int32)), 8).up(3).n == 54      # children at +-4: inside
+    assert pcc.CoordMap(dev(np.array([[0, 129992, -129992, 0], [1, 8, 8, 8]], np.int32)), 8).up(3).n == 54      # children at +-4: inside
     cb = np.concatenate([c, np.array([bad], np.int32)])
     with pytest.raises(ValueError, match="outside the supported range"):
         pcc.CoordMap(dev(cb), 1).down()
@@ -112,11 +112,11 @@ def test_coordinates_outside_the_key_range_are_an_error_not_an_alias(pcc, model_
 
 def test_children_beyond_the_key_range_are_reported(pcc):
     """a parent at the limit whose generated children step over it"""
-    c = np.array([[0, 31996, 0, 0], [0, 0, 0, 0]], np.int32)
+    c = np.array([[0, 129996, 0, 0], [0, 0, 0, 0]], np.int32)
     assert pcc.CoordMap(dev(c), 4).up(2).n == 16                                  # children at +0 / +2: inside
-    c[0, 1] = 32000
+    c[0, 1] = 130000
     with pytest.raises(ValueError, match="outside the supported range"):
-        pcc.CoordMap(dev(c), 8).up(3)                                             # a child at 32004
+        pcc.CoordMap(dev(c), 8).up(3)                                             # a child at 130004
 
 
 @pytest.fixture(scope="module")
