@@ -76,6 +76,49 @@ class ScaledBlock(nn.Module):
 
 
 _SIDE_STREAMS = {}
+_HELPERS = {}
+
+
+class _PrefetchHelper:
+    """One helper thread per coding thread.  Building an up block's coordinate set reads a row count back from the device; on the
+    coding thread that read stopped the enqueueing of the main stream's own work (q_predict, ScaledBlock) for as long as the GPU
+    needed to reach it — the chip then ran dry behind every prune.  The helper makes the same calls on the side stream and does the
+    waiting; the coding thread goes on and meets it at _join_prefetch."""
+
+    def __init__(self, device):
+        import queue
+        import threading
+        self.jobs = queue.SimpleQueue()
+        self.device = device
+        self.thread = threading.Thread(target=self._run, name="pcc-map-prefetch", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        torch.cuda.set_device(self.device)          # a new thread starts on device 0
+        while True:
+            fn, done = self.jobs.get()
+            try:
+                with torch.no_grad():               # (grad mode is per thread too)
+                    fn()
+            except BaseException as e:              # re-raised on the coding thread at the join
+                done.err = e
+            done.set()
+
+    def submit(self, fn):
+        import threading
+        done = threading.Event()
+        done.err = None
+        self.jobs.put((fn, done))
+        return done
+
+
+def _helper(device):
+    import threading
+    key = (threading.get_ident(), device)
+    h = _HELPERS.get(key)
+    if h is None:
+        h = _HELPERS[key] = _PrefetchHelper(device)
+    return h
 
 
 def prefetch_up_maps(x_map):
@@ -83,7 +126,8 @@ def prefetch_up_maps(x_map):
     ``x_map`` (candidates = k3 children; parent->candidate map; candidate->candidate maps).  They are pure
     functions of the coordinates, cached on the CoordMaps, and made of hash probes and sorts — memory-
     latency work that runs beside the MFMA-bound convolutions of the same stage (q_predict, ScaledBlock)
-    instead of in front of the up block.  Inference path only.
+    instead of in front of the up block.  The calls are made by a helper thread (_PrefetchHelper), which also does the
+    waiting for the candidates' row count.  Inference path only.
 
     Allocator note: everything allocated here belongs to the side stream's pool; a freed block can only be
     handed out again by a later prefetch, which starts with ``side.wait_stream(main)`` — after every main-
@@ -101,13 +145,25 @@ def prefetch_up_maps(x_map):
         side = _SIDE_STREAMS[skey] = torch.cuda.Stream(device=dev)
     x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
     side.wait_stream(main)
-    with torch.cuda.stream(side):
-        cand = x_map.up(3)
-        x_map.mfma_kernel_map(cand, 3, True)
-        cand.mfma_kernel_map(cand, 3)
-        cand.kernel_map(cand, 3)
-        x_map._cache[("prefetch_event",)] = side.record_event()
+
+    def job():
+        with torch.cuda.stream(side):
+            cand = x_map.up(3)
+            x_map.mfma_kernel_map(cand, 3, True)
+            cand.mfma_kernel_map(cand, 3)
+            cand.kernel_map(cand, 3)
+            x_map._cache[("prefetch_event",)] = side.record_event()
+
+    if PREFETCH_THREAD and x_map.n >= PREFETCH_THREAD_MIN_ROWS:
+        x_map._cache[("prefetch_job",)] = _helper(dev).submit(job)
+    else:
+        job()
     x_map._cache[key] = True
+
+
+# PCC_PREFETCH_THREAD=0: the up blocks' prefetch calls are made (and their row count waited for) on the coding thread (A/B)
+PREFETCH_THREAD = os.environ.get("PCC_PREFETCH_THREAD", "1") == "1"
+PREFETCH_THREAD_MIN_ROWS = 8192          # below: the hand-over costs more than the wait (the 4.9 k-point frame: 5.4 -> 5.7 ms with it)
 
 
 def prefetch_analysis_maps(x_map, levels=5, hyper_ups=2):
@@ -151,6 +207,11 @@ def prefetch_analysis_maps(x_map, levels=5, hyper_ups=2):
 
 
 def _join_prefetch(x_map):
+    done = x_map._cache.pop(("prefetch_job",), None)
+    if done is not None:
+        done.wait()
+        if done.err is not None:
+            raise done.err
     ev = x_map._cache.pop(("prefetch_event",), None)
     if ev is not None:
         torch.cuda.current_stream(x_map.device).wait_event(ev)
@@ -185,7 +246,9 @@ class GenerativeUpBlock(nn.Module):
         pred = self.occ_predict(x, last_out_channels=None if full_predictions else 1)
         nb = x.map._nbatch if x.map._nbatch is not None else x.map.nbatch
         mask = sp.topk_mask(pred.F, pred.C, k, nb)
-        coords_kept, feats_kept, _, _ = sp.compact_rows(mask, x.C, x.F)
+        # one item: the selection keeps exactly min(k, candidates) rows (ties are broken by coordinate) — no count to wait for
+        kept = min(max(int(k[0]), 0), x.map.n) if nb == 1 and len(k) == 1 and not torch.is_grad_enabled() else None
+        coords_kept, feats_kept, _, _ = sp.compact_rows(mask, x.C, x.F, expected=kept)
         up_map = CoordMap(coords_kept, x.map.stride, nbatch=x.map._nbatch)
         x = SparseTensor(feats_kept, coordinate_map=up_map)
         if not self.dense and self.condition_ablation is None:

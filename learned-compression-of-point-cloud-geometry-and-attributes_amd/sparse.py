@@ -531,8 +531,11 @@ def scatter_rows(src, idx, n_out):
     return out
 
 
-def compact_rows(mask, coords=None, feats=None, want_index=False):
-    """Order-preserving compaction (ME.MinkowskiPruning).  Returns (coords, feats, new_index, n)."""
+def compact_rows(mask, coords=None, feats=None, want_index=False, expected=None):
+    """Order-preserving compaction (ME.MinkowskiPruning).  Returns (coords, feats, new_index, n).
+
+    ``expected``: the number of set mask bytes when the caller knows it (a top-k selection of one item keeps exactly min(k, n) rows):
+    the count is then not read back (PCC_CHECK_COUNTS=1 reads and compares it) — the coding thread does not stop enqueueing."""
     if _tracked(feats):
         feats_k, coords_k, new_index = _CompactFeatsFn.apply(feats, mask, coords)
         return (coords_k if coords is not None else None), feats_k, (new_index if want_index else None), feats_k.shape[0]
@@ -540,7 +543,8 @@ def compact_rows(mask, coords=None, feats=None, want_index=False):
     n = mask.shape[0]
     dev = mask.device
     scratch = torch.empty(L.pcc_scan_scratch_elems(n), dtype=torch.int32, device=dev)
-    count = _host_count()
+    known = expected is not None and n > 0 and not CHECK_EXPECTED_COUNTS
+    count = None if known else _host_count()
     out_c = torch.empty((n, 4), dtype=torch.int32, device=dev) if coords is not None else None
     c = feats.shape[1] if feats is not None else 0
     out_f = torch.empty((n, c), dtype=torch.float32, device=dev) if feats is not None else None
@@ -548,7 +552,12 @@ def compact_rows(mask, coords=None, feats=None, want_index=False):
     ev = _cp_begin()
     check(L.pcc_compact_rows(ptr(mask), n, ptr(coords), ptr(out_c), ptr(feats), c, ptr(out_f), ptr(new_index),
                              ptr(scratch), ptr(count), _lib.stream()))
-    m = _read_count(count, dev)
+    if known:
+        m = int(expected)
+    else:
+        m = _read_count(count, dev)
+        if expected is not None and m != int(expected):
+            raise RuntimeError(f"compact_rows: {m} rows kept where the caller expected {int(expected)}")
     # mask + scan per row, coordinates and features of the kept rows read and written
     _cp_end(ev, "prune", n, 13 * n + (2 * (16 if coords is not None else 0) + 8 * c) * m)
     return (out_c[:m] if out_c is not None else None, out_f[:m] if out_f is not None else None, new_index, m)
@@ -723,6 +732,8 @@ NARROW_HEAD_MAX_COUT = 4
 
 # Spatial block size (log2, in voxels of the map's stride) inside which rows are ordered by neighbour
 # mask; -1 = order by mask over the whole map (best MFMA tile occupancy, least gather locality).
+# PCC_CHECK_COUNTS=1: read back (and compare) the row counts a caller passes as known instead of trusting them (A/B, tests)
+CHECK_EXPECTED_COUNTS = os.environ.get("PCC_CHECK_COUNTS", "0") == "1"
 ORDER_BLOCK_LOG2 = int(os.environ.get("PCC_ORDER_BLOCK_LOG2", "-1"))
 
 # Opt-in reduced-precision inference (never the default, never the headline number): convolutions whose input width
