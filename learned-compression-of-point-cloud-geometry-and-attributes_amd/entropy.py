@@ -87,8 +87,14 @@ def _pmf_to_cdf(pmf, tail, pmf_length, max_length):
 _PINNED = {}
 
 
+_PIN_BUSY = {}      # (thread, key) -> event recorded behind the last asynchronous upload FROM that staging buffer
+
+
 def _pinned(key, numel, dtype):
     key = (threading.get_ident(), key)         # one staging set per worker thread (streamed sequences: one thread per frame in flight)
+    ev = _PIN_BUSY.pop(key, None)
+    if ev is not None:
+        ev.synchronize()                       # the previous upload from this buffer (long done by now) before it is rewritten
     buf = _PINNED.get(key)
     if buf is None or buf.numel() < numel or buf.dtype != dtype:
         buf = torch.empty(max(numel, 1), dtype=dtype, pin_memory=True)
@@ -115,14 +121,81 @@ def _to_host_async(t, key):
     return buf.numpy().reshape(t.shape), ev
 
 
+def _upload_guard(key, device):
+    """the staging buffer ``key`` of this thread has an upload in flight on the current stream: its next user waits for THAT (an event),
+    not the uploader for the whole stream — a stream wait here stopped the coding thread until the GPU had drained everything queued
+    (the kernel maps in front of h_s, the prefetched maps in front of g_s) and the chip then idled while the thread caught up"""
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    _PIN_BUSY[(threading.get_ident(), key)] = ev
+
+
 def _to_device(arr, device, key):
     """numpy array -> device tensor through a pinned staging buffer."""
     src = torch.from_numpy(np.ascontiguousarray(arr))
     buf = _pinned(key, src.numel(), src.dtype)
     buf.copy_(src.reshape(-1))
     out = buf.to(device, non_blocking=True).reshape(src.shape)
-    torch.cuda.current_stream(out.device).synchronize()    # the staging buffer is reused by the next call
+    _upload_guard(key, out.device)
     return out
+
+
+class _HostWorker:
+    """A persistent thread per coding thread for the serial range-coder calls that run beside GPU work (the C calls release the
+    interpreter lock).  Creating a thread per call cost the coding thread ~0.3 ms at the start of every decode (thread start + the new
+    thread's Python prelude under the lock) — on the critical path, with the GPU idle."""
+
+    def __init__(self):
+        import queue
+        self.jobs = queue.SimpleQueue()
+        self.thread = threading.Thread(target=self._run, name="pcc-rans", daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while True:
+            fn, done = self.jobs.get()
+            try:
+                fn()
+            except BaseException as e:      # re-raised on the coding thread by wait()
+                done.err = e
+            done.set()
+
+    def submit(self, fn):
+        done = threading.Event()
+        done.err = None
+        self.jobs.put((fn, done))
+        return done
+
+
+_WORKERS = {}
+
+
+def _host_worker():
+    key = threading.get_ident()
+    w = _WORKERS.get(key)
+    if w is None:
+        w = _WORKERS[key] = _HostWorker()
+    return w
+
+
+def _wait(done):
+    done.wait()
+    if done.err is not None:
+        raise done.err
+
+
+_CHANNEL_INDEX_PLANES = {}
+
+
+def _channel_index_plane(c, n):
+    """np.repeat(np.arange(c), n) as int32 (the factorized model's indexes: channel-major planes), cached: 150 k elements per decode"""
+    key = (c, n)
+    hit = _CHANNEL_INDEX_PLANES.get(key)
+    if hit is None:
+        if len(_CHANNEL_INDEX_PLANES) > 64:
+            _CHANNEL_INDEX_PLANES.clear()
+        hit = _CHANNEL_INDEX_PLANES[key] = np.repeat(np.arange(c, dtype=np.int32), n)
+    return hit
 
 
 def _rans_encode(symbols, indexes, cdf, cdf_length, offset):
@@ -257,7 +330,13 @@ class EntropyBottleneck(_EntropyModelBase):
         return torch.abs(logits - self.target).sum()
 
     def medians(self):
-        return self.quantiles[:, 0, 1].detach().contiguous()
+        q = self.quantiles
+        key = (q._version, q.data_ptr())
+        hit = self.__dict__.get("_medians_cache")
+        if hit is None or hit[0] != key:
+            hit = (key, q[:, 0, 1].detach().contiguous())          # (a strided slice: one small copy kernel per parameter version)
+            self.__dict__["_medians_cache"] = hit
+        return hit[1]
 
     @torch.no_grad()
     def update(self, force=False):
@@ -382,25 +461,28 @@ class EntropyBottleneck(_EntropyModelBase):
         """Start the (host, serial) range decode of z on a worker thread — it needs nothing from the GPU — and return a
         function that joins it and dequantises: in between the caller builds the coordinate sets and kernel maps that
         depend on coordinates only."""
-        import threading
         cdf, cdf_len, off = self.tables()
         c = self.channels
         box = {}
+        indexes = _channel_index_plane(c, n)
+        # everything the call needs is prepared HERE: the worker's job is the C call alone (it releases the interpreter lock; Python
+        # steps on the worker would each queue for the lock this thread holds while it builds the kernel maps)
+        buf = np.frombuffer(strings[0], dtype=np.uint8)
+        sym_host = _pinned("eb_sym32", c * n, torch.int32)          # decoded straight into the page-locked plane the upload reads
+        out = sym_host.numpy()
+        fn = _lib.lib().pcc_rans_decode_with_indexes
+        args = (ptr(buf), len(strings[0]), ptr(indexes), indexes.size, ptr(cdf), cdf.shape[1], ptr(cdf_len), ptr(off), ptr(out))
 
         def work():
-            try:
-                box["sym"] = _rans_decode(strings[0], np.repeat(np.arange(c, dtype=np.int32), n), cdf, cdf_len, off)
-            except BaseException as e:      # re-raised on the caller's thread
-                box["err"] = e
+            box["rc"] = fn(*args)
 
-        th = threading.Thread(target=work, name="pcc-rans-decode-z")
-        th.start()
+        done = _host_worker().submit(work)
 
         def finish():
-            th.join()
-            if "err" in box:
-                raise box["err"]
-            sym = torch.from_numpy(box["sym"].reshape(c, n)).to(device)
+            _wait(done)
+            check(box["rc"])
+            sym = sym_host.to(device, non_blocking=True).reshape(c, n)
+            _upload_guard("eb_sym32", device)
             zhat = torch.empty((n, c), dtype=torch.float32, device=device)
             check(_lib.lib().pcc_eb_dequantize(ptr(sym), n, c, ptr(self.medians().to(device)), ptr(zhat), _lib.stream()))
             return zhat
@@ -532,27 +614,31 @@ class GaussianConditional(_EntropyModelBase):
         cdf, cdf_len, off = self.tables()
         box = {}
 
-        def work():
-            try:
-                idx_ev.synchronize()
-                box["fits"] = _rans_decode_packed(strings[0], idx_host, cdf, cdf_len, off, sym_host.numpy())
-                if not box["fits"]:                                              # a symbol beyond int16: int32 planes
-                    box["sym"] = _rans_decode(strings[0], idx_host.astype(np.int32), cdf, cdf_len, off)
-            except BaseException as e:      # re-raised on the caller's thread
-                box["err"] = e
+        # (arguments prepared here, the worker's job is the event wait and the C call: see the factorized model's decode)
+        buf = np.frombuffer(strings[0], dtype=np.uint8)
+        narrowed = np.zeros(1, dtype=np.int32)
+        sym_np = sym_host.numpy()
+        fn = _lib.lib().pcc_rans_decode_with_indexes_u8i16
+        args = (ptr(buf), len(strings[0]), ptr(idx_host), idx_host.size, ptr(cdf), cdf.shape[1], ptr(cdf_len), ptr(off), ptr(sym_np), ptr(narrowed))
 
-        th = threading.Thread(target=work, name="pcc-rans-decode")
-        th.start()
+        def work():
+            idx_ev.synchronize()
+            check(fn(*args))
+            box["fits"] = int(narrowed[0]) == 0
+            if not box["fits"]:                                              # a symbol beyond int16: int32 planes
+                box["sym"] = _rans_decode(strings[0], idx_host.astype(np.int32), cdf, cdf_len, off)
+
+        done = _host_worker().submit(work)
 
         def finish():
-            th.join()
+            _wait(done)
             if "err" in box:
                 raise box["err"]
             yhat = torch.empty((n, c), dtype=torch.float32, device=dev)
             if box["fits"]:
                 sym = sym_host.to(dev, non_blocking=True)
+                _upload_guard("gc_sym16", dev)                                   # the pinned plane is reused by the next frame
                 check(_lib.lib().pcc_gc_dequantize_i16(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))
-                torch.cuda.current_stream(dev).synchronize()                     # the pinned plane is reused by the next frame
             else:
                 sym = _to_device(box["sym"].reshape(c, n), dev, "gc_sym_up")
                 check(_lib.lib().pcc_gc_dequantize(ptr(sym), ptr(params.contiguous()), n, c, ptr(yhat), _lib.stream()))

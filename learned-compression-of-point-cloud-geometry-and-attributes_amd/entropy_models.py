@@ -215,7 +215,11 @@ class MeanScaleHyperprior_Map(nn.Module):
         y_strings, z_strings = strings
         # the z stream needs nothing from the GPU: its host decode runs while the GPU builds what depends on coordinates
         # only — the tables and kernel maps of h_s (z -> 16 -> 8, evaluated at y) and of the first h_q layer
-        finish_z = self.entropy_bottleneck.decompress_features_async(z_strings, int(shape[0]), z_sorted.device)
+        early = self.__dict__.pop("_early_z", None)                   # ColorModel.decompress starts it before the coordinate sets
+        if early is not None and early[0] is strings:                 # (a decode started for THESE strings: an earlier call may have failed)
+            finish_z = early[1]
+        else:
+            finish_z = self.entropy_bottleneck.decompress_features_async(z_strings, int(shape[0]), z_sorted.device)
         z_sorted.mfma_kernel_map(z_sorted, 3)
         z16 = z_sorted.up(2)
         z_sorted.mfma_kernel_map(z16, 2, True)
@@ -232,6 +236,11 @@ class MeanScaleHyperprior_Map(nn.Module):
         self._prefetch_synthesis_maps(y_sorted, Q_hat.map)
         y_hat_f = finish_y()
         return SparseTensor(y_hat_f, coordinate_map=y_sorted), Q_hat
+
+    def start_z_decode(self, strings, shape, device):
+        """The z stream needs nothing but its bytes: its host decode (0.6-0.8 ms on the config-2 frame) can start before the first
+        coordinate set of a decompress is built; decompress() picks the pending result up."""
+        self.__dict__["_early_z"] = (strings, self.entropy_bottleneck.decompress_features_async(strings[1], int(shape[0]), device))
 
     @staticmethod
     def _prefetch_synthesis_maps(y_map, q_map):

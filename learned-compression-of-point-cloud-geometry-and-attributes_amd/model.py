@@ -131,6 +131,8 @@ class ColorModel(nn.Module):
             batch = torch.zeros((coordinates.shape[0], 1), device=device, dtype=coordinates.dtype)
             coordinates = torch.cat([batch, coordinates], dim=1)
         nbatch = len(k[0]) if isinstance(k[0], (list, tuple)) else 1          # one count per item and stage
+        if self.entropy_model_map is None:
+            self.entropy_model.start_z_decode(strings, shape, device)           # host work that needs no coordinates: first
         c8 = CoordMap(sp._as_int_coords(coordinates.to(device)), 8, nbatch=nbatch)
         c32 = c8.down().down()      # coordinates only (g_s.down_conv applied twice, model.py:188-190)
         if self.entropy_model_map is None:
