@@ -90,9 +90,9 @@ class MeanScaleHyperprior(nn.Module):
         finish_z, z_hat_f = self.entropy_bottleneck.compress_features_begin(z.F, perm=perm_z)
         z_hat = SparseTensor(z_hat_f, coordinate_map=z.map)
         finish_y = self.gaussian_conditional.compress_features_begin(y.F, self._params_at(z_hat, y.map), perm=perm_y)
+        points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
         z_strings = finish_z()
         y_strings = finish_y()
-        points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
         return points, [y_strings, z_strings], shape
 
     def decompress(self, points, strings, shape):
@@ -196,9 +196,10 @@ class MeanScaleHyperprior_Map(nn.Module):
         z_hat = SparseTensor(z_hat_f, coordinate_map=z.map)
         params = self._params_at(z_hat, y.map)
         finish_y = self.gaussian_conditional.compress_features_begin(y.F, params, perm=perm_y)
+        # (the sorted point lists are enqueued before the host starts coding: behind it they were four small launches at the very end)
+        points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
         z_strings = finish_z()
         y_strings = finish_y()
-        points = [y.C.index_select(0, perm_y.long()), z.C.index_select(0, perm_z.long())]
         return points, [y_strings, z_strings], shape
 
     def decompress(self, points, strings, shape):
