@@ -340,6 +340,35 @@ def test_translated_clouds_code_to_the_same_bytes_up_to_the_reference_key_range(
         assert np.array_equal(a[:, :3], b[:, :3] + off) and np.array_equal(a[:, 3:], b[:, 3:]), off
 
 
+def test_an_error_inside_the_prefetch_helper_thread_reaches_the_caller(pcc, model, monkeypatch):
+    """the up blocks' coordinate sets are generated by a helper thread (blocks._PrefetchHelper): whatever is raised there must surface
+    at the join on the coding thread, and the helper must go on serving jobs.  (A range error cannot be provoked through the codec
+    itself: wherever the encoder's coordinate sets fit the key range the decoder's do too.)"""
+    from pcc_amd import blocks
+    dev = torch.device(DEV)
+    m = pcc.CoordMap(torch.tensor([[0, 8, 8, 8], [0, 16, 8, 8]], dtype=torch.int32, device=dev), 8, nbatch=1)
+    helper = blocks._helper(dev)
+    def failing_job():
+        m.table()                                                              # (real work on the side thread first)
+        raise pcc.sparse.CoordinateRangeError("raised on the helper thread")
+    m._cache[("prefetch_job",)] = helper.submit(failing_job)
+    with pytest.raises(ValueError, match="raised on the helper thread"):
+        blocks._join_prefetch(m)
+    assert ("prefetch_job",) not in m._cache
+    done = helper.submit(lambda: m.up(3))                                     # the same thread serves the next job
+    done.wait()
+    assert done.err is None and m.up(3).n == 2 * 27 - 9
+    # and through the codec, with the helper forced on for a tiny cloud: same bytes, same reconstruction as in line
+    monkeypatch.setattr(blocks, "PREFETCH_THREAD_MIN_ROWS", 0)
+    pts = pcc.synthetic.sphere_shell(**pcc.synthetic.CONFIG1)
+    qc, qf = pcc.synthetic.uniform_qmap(pts[:, :3], 0.5, 0.5)
+    strings, shape, k, coords = _compress(pcc, model, pts, qc, qf)
+    rec_t = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k).cpu().numpy()
+    monkeypatch.setattr(blocks, "PREFETCH_THREAD", False)
+    rec_i = model.decompress(coordinates=coords, strings=strings, shape=shape, k=k).cpu().numpy()
+    assert np.array_equal(rec_t, rec_i)
+
+
 def test_duplicate_input_points_are_an_error(pcc, model):
     """two points in one voxel: ME's SparseTensor constructor (model/model.py:121) would keep an unspecified one of them, so there is
     no result to reproduce — compress says so instead of coding a cloud with an orphan row; the de-duplicated cloud codes as usual"""
