@@ -68,6 +68,57 @@ def kernel_source_sha256():
     return h.hexdigest()
 
 
+LIVE_PMC_FLAGS = ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-blocks-record", "--no-x3-record", "--no-streamed-record",
+                  "--no-small-frame-record", "--no-mid-frame-record", "--no-train-record", "--no-hbm-record", "--no-live-pmc"]
+
+
+def live_traffic(kernel_substr, timeout_s=150):
+    """HBM bytes per launch of the dominant kernel MEASURED IN THIS RUN: two child processes — `rocprofv3 --pmc FETCH_SIZE` and
+    `--pmc WRITE_SIZE`, separate passes with the kernel trace only beside them, the program itself after `--`, as
+    MI355X_MICROARCH.md prescribes — of this same script on the same workload (3 steps), reduced like tools/pmc_traffic.py
+    (FETCH_SIZE x 2 on gfx950, KB -> bytes, averaged over the kernel's launches).  -> dict, or a string saying why not."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return "rocprofv3 not on PATH"
+    if "rocprof" in os.environ.get("LD_PRELOAD", "") or os.environ.get("ROCPROFILER_SDK_TOOL_LIBRARIES") or os.environ.get("ROCP_TOOL_LIBRARIES"):
+        return "this process is itself being profiled"
+    out = {}
+    root = tempfile.mkdtemp(prefix="pcc_live_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(root, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
+                   "python3", os.path.abspath(__file__)] + LIVE_PMC_FLAGS
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                return f"the {counter} pass did not finish in {timeout_s} s"
+            if r.returncode != 0:
+                return f"the {counter} pass failed (rc {r.returncode}): " + r.stderr.decode(errors="replace")[-300:]
+            files = glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True)
+            if not files:
+                return f"the {counter} pass wrote no counter file"
+            per = {}
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return f"the {counter} pass saw no launch of {kernel_substr}"
+            out[counter] = (len(per), sum(per.values()) / len(per) * 1024.0)
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+    fb, wb = out["FETCH_SIZE"][1] * 2.0, out["WRITE_SIZE"][1]
+    return {"traffic_bytes_per_launch": fb + wb, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+            "launches_fetch_pass": out["FETCH_SIZE"][0], "launches_write_pass": out["WRITE_SIZE"][0],
+            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py " + " ".join(LIVE_PMC_FLAGS)}
+
+
 def free_port():
     """a TCP port nobody listens on right now (rendezvous of a self-launched run; fixed ports collide between
     concurrent runs on one host)"""
@@ -198,6 +249,8 @@ def parse():
     ap.add_argument("--no-mid-frame-record", action="store_true", help="skip the `mid_frame` sub-record of a default run")
     ap.add_argument("--no-train-record", action="store_true", help="skip the `train_step` sub-record of a default run")
     ap.add_argument("--no-hbm-record", action="store_true", help="skip the `roofline_hbm` record of a default run")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic in this run (two rocprofv3 --pmc child passes, ~40 s): replay the committed figure")
     ap.add_argument("--file-mode", action="store_true",
                     help="after the timed region, also time compress(path=...) / decompress(path=...) (t_file, SURVEY.md 8d)")
     return ap.parse_args()
@@ -903,6 +956,22 @@ def main():
                            "kernel_source_unchanged_since": tj.get("kernel_source_sha256") == kernel_source_sha256(),
                            "how": "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, FETCH x2 gfx950 "
                                   "correction (tools/pmc_traffic.py); replayed from the committed file, not measured in this run"}
+        # ... unless it can be measured here and now (default N = 1 run): the same two passes as children of this process
+        if (traffic_src is not None and rank == 0 and world == 1 and not args.no_live_pmc and not args.bf16 and not args.x3
+                and not blocks_mode and not args.weights and os.environ.get("PCC_BENCH_MARK") != "1"):
+            print("[bench] roofline.traffic: two rocprofv3 --pmc child passes ...", file=sys.stderr, flush=True)
+            live = live_traffic(dom_name.rstrip(">"))
+            if isinstance(live, dict):
+                replayed = traffic
+                traffic = live["traffic_bytes_per_launch"]
+                traffic_src = {"how": "MEASURED IN THIS RUN: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (kernel trace only beside them) "
+                                      "of this command as child processes, FETCH x2 gfx950 correction, averaged over the kernel's launches",
+                               "command": live["command"], "fetch_bytes_per_launch": live["fetch_bytes_per_launch"],
+                               "write_bytes_per_launch": live["write_bytes_per_launch"], "launches": [live["launches_fetch_pass"], live["launches_write_pass"]],
+                               "committed_figure": {"file": traffic_src["file"], "traffic_bytes_per_launch": replayed,
+                                                    "kernel_source_unchanged_since": traffic_src["kernel_source_unchanged_since"]}}
+            else:
+                traffic_src["live_measurement_skipped"] = live
         peak = MFMA_BF16_PEAK_TFLOPS if "[bf16]" in dom_name else MFMA_F32_PEAK_TFLOPS
         if "[x3]" in dom_name:
             peak = MFMA_BF16_PEAK_TFLOPS / 6.0      # six bf16 products per algorithmic multiply-add

@@ -3,7 +3,7 @@
 # into encode / decode windows by tools/trace_gaps.py; plus rocprofv3 --stats of the config-2 command.
 #   gpurun --timeout 900 -- "bash tools/gpu_anatomy_job.sh [tag]"
 TAG=${1:-r4}
-OFF="--no-cpu-baseline --no-blocks-record --no-x3-record --no-streamed-record --no-small-frame-record --no-mid-frame-record --no-train-record --no-hbm-record"
+OFF="--no-cpu-baseline --no-blocks-record --no-x3-record --no-streamed-record --no-small-frame-record --no-mid-frame-record --no-train-record --no-hbm-record --no-live-pmc"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_stats -o b -- python3 $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 $OFF > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_bench_under_rocprof.log 2>&1; echo "stats rc=$?"
 PCC_BENCH_MARK=1 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof_marked -o b -- python3 $GRAFT_REPO_ROOT/bench.py $OFF > /dev/null 2>&1; echo "marked rc=$?"

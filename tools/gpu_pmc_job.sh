@@ -11,7 +11,7 @@ TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 pass() {   # name, counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-blocks-record --no-x3-record --no-streamed-record --no-small-frame-record --no-mid-frame-record --no-train-record --no-hbm-record > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name.log 2>&1
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-blocks-record --no-x3-record --no-streamed-record --no-small-frame-record --no-mid-frame-record --no-train-record --no-hbm-record --no-live-pmc > $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name.log 2>&1
   rc=$?
   echo "pmc $name rc=$rc"
   rm -f $GRAFT_REPO_ROOT/gpurun_out/${TAG}_pmc_$name/*.db

@@ -5,7 +5,7 @@
 TAG=${1:-r3}
 set -x
 python tools/train.py --steps 1500 --bf16 --log-every 250 --out /tmp/w2min.pt 2>&1 | tail -8
-PCC_BENCH_TOP=14 python bench.py --weights /tmp/w2min.pt --no-cpu-baseline --no-blocks-record --no-train-record --no-mid-frame-record --no-hbm-record --breakdown > gpurun_out/${TAG}_bench_trained.json 2> gpurun_out/${TAG}_bench_trained.err
+PCC_BENCH_TOP=14 python bench.py --weights /tmp/w2min.pt --no-cpu-baseline --no-blocks-record --no-train-record --no-mid-frame-record --no-hbm-record --no-live-pmc --breakdown > gpurun_out/${TAG}_bench_trained.json 2> gpurun_out/${TAG}_bench_trained.err
 grep -E "conv_mfma|conv total|rows" gpurun_out/${TAG}_bench_trained.err | head -24
 TAG=$TAG python - <<'PY'
 import json, os
