@@ -99,3 +99,13 @@ def test_default_line_carries_the_committed_blas_order_baseline():
     assert main["parity"]["oracle_summation_order"] == "kernel" and main["parity"]["streams_byte_equal"] is True
     assert main["parity"]["decoded_voxels_differing"] == 0 and main["parity"]["colours_differing"] == 0
     assert main["value"] > 2 * blas["cpu_baseline"]["value"]
+
+
+def test_live_traffic_measurement_declines_inside_a_profiled_process(monkeypatch):
+    """bench.py measures roofline.traffic itself (two rocprofv3 --pmc child passes of its own command) — but never from a process
+    that is being profiled already (a nested profiler would be the exec-after-GPU-init the pool forbids), and its child command
+    carries --no-live-pmc so that it cannot recurse"""
+    import bench
+    monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    assert bench.live_traffic("conv_mfma_buf_kernel<64, 128, 2, 2, 4, true") == "this process is itself being profiled"
+    assert "--no-live-pmc" in bench.LIVE_PMC_FLAGS and "--no-cpu-baseline" in bench.LIVE_PMC_FLAGS
