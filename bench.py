@@ -111,12 +111,46 @@ def live_traffic(kernel_substr, timeout_s=150):
             if not per:
                 return f"the {counter} pass saw no launch of {kernel_substr}"
             out[counter] = (len(per), sum(per.values()) / len(per) * 1024.0)
+        # third pass: matrix-pipe busy cycles and the delivered clock of the same launches (tools/pmc_mfma.py's quotient:
+        # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / launch duration).
+        # Optional: its failure leaves the traffic figures standing.
+        try:
+            d = os.path.join(root, "MFMA")
+            cmd = ["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "--kernel-trace", "--output-format", "csv", "-d", d,
+                   "-o", "p", "--", "python3", os.path.abspath(__file__)] + LIVE_PMC_FLAGS
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=timeout_s)
+            cc = glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True)
+            kt = glob.glob(os.path.join(d, "**", "p_kernel_trace.csv"), recursive=True)
+            if r.returncode == 0 and cc and kt:
+                dur = {}
+                with open(kt[0]) as f:
+                    for row in csv.DictReader(f):
+                        if kernel_substr in row["Kernel_Name"]:
+                            dur[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
+                busy = gui = 0.0
+                with open(cc[0]) as f:
+                    for row in csv.DictReader(f):
+                        if row["Dispatch_Id"] in dur:
+                            if row["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES":
+                                busy += float(row["Counter_Value"])
+                            elif row["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                                gui += float(row["Counter_Value"])
+                secs = sum(dur.values())
+                if dur and gui > 0 and secs > 0:
+                    gui /= 8.0
+                    out["MFMA"] = {"mfma_busy_frac": busy / (gui * 1024.0), "delivered_clock_ghz": gui / secs / 1e9,
+                                   "mfma_busy_frac_of_2p4ghz": busy / 1024.0 / (secs * 2.4e9), "launches_mfma_pass": len(dur)}
+        except Exception:
+            pass
     finally:
         shutil.rmtree(root, ignore_errors=True)
     fb, wb = out["FETCH_SIZE"][1] * 2.0, out["WRITE_SIZE"][1]
-    return {"traffic_bytes_per_launch": fb + wb, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
-            "launches_fetch_pass": out["FETCH_SIZE"][0], "launches_write_pass": out["WRITE_SIZE"][0],
-            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace --output-format csv -- python3 bench.py " + " ".join(LIVE_PMC_FLAGS)}
+    res = {"traffic_bytes_per_launch": fb + wb, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+           "launches_fetch_pass": out["FETCH_SIZE"][0], "launches_write_pass": out["WRITE_SIZE"][0],
+           "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> --kernel-trace --output-format csv -- "
+                      "python3 bench.py " + " ".join(LIVE_PMC_FLAGS)}
+    res.update(out.get("MFMA", {}))
+    return res
 
 
 def free_port():
@@ -947,7 +981,7 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         # HBM traffic per launch comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this
         # same command, reduced by tools/pmc_traffic.py and committed under profiles/
-        traffic, traffic_src = None, None
+        traffic, traffic_src, live_pmc = None, None, None
         tj = latest_profile("traffic_dominant_kernel")
         if args.workload == "config2" and tj is not None and tj["kernel"] in dom_name:
             traffic = tj["traffic_bytes_per_launch"]
@@ -961,6 +995,7 @@ def main():
                 and not blocks_mode and not args.weights and os.environ.get("PCC_BENCH_MARK") != "1"):
             print("[bench] roofline.traffic: two rocprofv3 --pmc child passes ...", file=sys.stderr, flush=True)
             live = live_traffic(dom_name.rstrip(">"))
+            live_pmc = live if isinstance(live, dict) else None
             if isinstance(live, dict):
                 replayed = traffic
                 traffic = live["traffic_bytes_per_launch"]
@@ -1015,6 +1050,17 @@ def main():
                                "--kernel-trace; busy share of SIMD-cycles at the delivered clock, and the same cycles against 2.4 GHz; "
                                "replayed from the committed file, not measured in this run"}
                     break
+        if roofline is not None and live_pmc is not None and "mfma_busy_frac" in live_pmc:
+            how = ("MEASURED IN THIS RUN: one rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE child pass of this command (kernel trace "
+                   "only beside it), over the dominant kernel's launches")
+            for key, src in (("mfma_busy_frac", "mfma_counter_source"), ("delivered_clock_ghz", "clock_source")):
+                committed = roofline.get(key)
+                roofline[key] = live_pmc[key]
+                roofline[src] = {"how": how, "launches": live_pmc["launches_mfma_pass"],
+                                 "committed_figure": {"value": committed, "file": (roofline.get(src) or {}).get("file")}}
+            roofline["mfma_busy_frac_of_2p4ghz"] = live_pmc["mfma_busy_frac_of_2p4ghz"]
+            roofline["peak_assumes_clock_ghz"] = 2.4
+            roofline["frac_at_delivered_clock"] = roofline["achieved"] / (roofline["peak"] * live_pmc["delivered_clock_ghz"] / 2.4)
     if args.breakdown and rank == 0:
         tot_ms = sum(c["ms"] for c in classes.values())
         for n_, c in sorted(classes.items(), key=lambda kv: -kv[1]["ms"]):
