@@ -103,11 +103,18 @@ def live_traffic(kernel_substr, timeout_s=150):
             files = glob.glob(os.path.join(d, "**", "p_counter_collection.csv"), recursive=True)
             if not files:
                 return f"the {counter} pass wrote no counter file"
-            per = {}
+            per, allk = {}, {}
             with open(files[0]) as f:
                 for row in csv.DictReader(f):
-                    if row["Counter_Name"] == counter and kernel_substr in row["Kernel_Name"]:
-                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+                    if row["Counter_Name"] != counter:
+                        continue
+                    v = float(row["Counter_Value"])
+                    a = allk.setdefault(row["Kernel_Name"], [set(), 0.0])          # every kernel: launches, KB over the whole pass
+                    a[0].add(row["Dispatch_Id"])
+                    a[1] += v
+                    if kernel_substr in row["Kernel_Name"]:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + v
+            out[counter + "_all"] = {k: (len(v[0]), v[1]) for k, v in allk.items()}
             if not per:
                 return f"the {counter} pass saw no launch of {kernel_substr}"
             out[counter] = (len(per), sum(per.values()) / len(per) * 1024.0)
@@ -150,6 +157,7 @@ def live_traffic(kernel_substr, timeout_s=150):
            "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE> --kernel-trace --output-format csv -- "
                       "python3 bench.py " + " ".join(LIVE_PMC_FLAGS)}
     res.update(out.get("MFMA", {}))
+    res["per_kernel_kb"] = {"FETCH_SIZE": out["FETCH_SIZE_all"], "WRITE_SIZE": out["WRITE_SIZE_all"], "steps_in_run": 4}      # warm-up 1 + 3 steps
     return res
 
 
@@ -1059,6 +1067,35 @@ def main():
                 roofline[src] = {"how": how, "launches": live_pmc["launches_mfma_pass"],
                                  "committed_figure": {"value": committed, "file": (roofline.get(src) or {}).get("file")}}
             roofline["mfma_busy_frac_of_2p4ghz"] = live_pmc["mfma_busy_frac_of_2p4ghz"]
+        if roofline_hbm is not None and live_pmc is not None and "per_kernel_kb" in live_pmc:
+            # the same FETCH_SIZE / WRITE_SIZE child passes, per kernel name, grouped by operator like tools/pmc_hbm_ops.py
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                from pmc_hbm_ops import operator_of, short
+                pk = live_pmc["per_kernel_kb"]
+                steps_run = pk["steps_in_run"]
+                per_op = {}
+                for name in set(pk["FETCH_SIZE"]) | set(pk["WRITE_SIZE"]):
+                    op = operator_of(name)
+                    if op is None:
+                        continue
+                    nf, f_kb = pk["FETCH_SIZE"].get(name, (0, 0.0))
+                    nw, w_kb = pk["WRITE_SIZE"].get(name, (0, 0.0))
+                    fb_, wb_ = f_kb * 1024 * 2 / steps_run, w_kb * 1024 / steps_run
+                    o = per_op.setdefault(op, {"hbm_bytes_per_step": 0.0, "kernels": {}})
+                    o["hbm_bytes_per_step"] += fb_ + wb_
+                    o["kernels"][short(name)] = {"launches_per_step": max(nf, nw) / steps_run, "fetch_bytes_per_step": fb_, "write_bytes_per_step": wb_}
+                for rec in roofline_hbm["operators"]:
+                    if rec["operator"] in per_op:
+                        rec["traffic"] = per_op[rec["operator"]]["hbm_bytes_per_step"]
+                        rec["traffic_kernels"] = per_op[rec["operator"]]["kernels"]
+                committed = roofline_hbm.get("traffic_source")
+                roofline_hbm["traffic_source"] = {
+                    "how": "MEASURED IN THIS RUN: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (roofline.traffic_source), "
+                           "per kernel name over the whole pass / its 4 steps, FETCH x2 gfx950 correction, grouped by operator (tools/pmc_hbm_ops.py)",
+                    "committed_file": None if committed is None else committed.get("file")}
+            except Exception as e:              # the replayed figures stay
+                roofline_hbm.setdefault("traffic_source", {})["live_measurement_skipped"] = repr(e)[:200]
             roofline["peak_assumes_clock_ghz"] = 2.4
             roofline["frac_at_delivered_clock"] = roofline["achieved"] / (roofline["peak"] * live_pmc["delivered_clock_ghz"] / 2.4)
     if args.breakdown and rank == 0:
