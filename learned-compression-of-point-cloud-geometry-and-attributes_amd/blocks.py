@@ -185,25 +185,83 @@ def prefetch_analysis_maps(x_map, levels=5, hyper_ups=2):
         side = _SIDE_STREAMS[skey] = torch.cuda.Stream(device=dev)
     x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
     side.wait_stream(main)
-    with torch.cuda.stream(side):
-        m, sets = x_map, [x_map]
-        for _ in range(levels):
-            d = m.down()
-            m.mfma_kernel_map(d, 3)                          # the stride-2 convolution onto the coarser set
-            d.mfma_kernel_map(d, 3)                          # the stride-1 convolutions on it
-            sets.append(d)
-            m = d
-        y_map = sets[3] if len(sets) > 3 else None           # stride 8: the latents' set; h_s ends on it
-        u = m
-        for _ in range(hyper_ups if y_map is not None and levels >= 5 else 0):
-            c = u.up(2)                                      # h_s: generative transposed convolutions, kernel 2
-            u.mfma_kernel_map(c, 2, True)
-            c.mfma_kernel_map(c, 3)
-            u = c
-        if y_map is not None and u is not m:
-            u.mfma_kernel_map(y_map, 3)                      # h_s's last layer, evaluated at the latents' coordinates
-        x_map._cache[("prefetch_event",)] = side.record_event()
+    import threading
+    # one (host event, stream event) pair per level and one for the rest: the coding thread takes level L's maps up as soon as THEY are
+    # there (join_analysis_level) and runs that level's convolutions while the helper goes on with the coarser ones — until round 4's
+    # end the main stream stood still for ~2.4 ms at the start of every encode, waiting for all levels behind a single event
+    syncs = [_LevelSync() for _ in range(levels + 1)]
+
+    def job():
+        try:
+            with torch.cuda.stream(side):
+                m, sets = x_map, [x_map]
+                for lv in range(levels):
+                    d = m.down()
+                    m.mfma_kernel_map(d, 3)                          # the stride-2 convolution onto the coarser set
+                    d.mfma_kernel_map(d, 3)                          # the stride-1 convolutions on it
+                    sets.append(d)
+                    m = d
+                    syncs[lv].publish(side.record_event())
+                y_map = sets[3] if len(sets) > 3 else None           # stride 8: the latents' set; h_s ends on it
+                u = m
+                for _ in range(hyper_ups if y_map is not None and levels >= 5 else 0):
+                    c = u.up(2)                                      # h_s: generative transposed convolutions, kernel 2
+                    u.mfma_kernel_map(c, 2, True)
+                    c.mfma_kernel_map(c, 3)
+                    u = c
+                if y_map is not None and u is not m:
+                    u.mfma_kernel_map(y_map, 3)                      # h_s's last layer, evaluated at the latents' coordinates
+                syncs[levels].publish(side.record_event())
+        except BaseException as e:
+            for sy in syncs:
+                sy.fail(e)
+            raise
+
+    x_map._cache[("analysis_syncs",)] = syncs
+    if PREFETCH_THREAD and x_map.n >= PREFETCH_THREAD_MIN_ROWS:
+        x_map._cache[("prefetch_job",)] = _helper(dev).submit(job)
+    else:
+        job()
     x_map._cache[key] = True
+
+
+class _LevelSync:
+    """what one level of prefetch_analysis_maps hands over: set once its maps are in the caches, with the side stream's event behind them"""
+
+    def __init__(self):
+        import threading
+        self.ready = threading.Event()
+        self.event = None
+        self.err = None
+
+    def publish(self, event):
+        self.event = event
+        self.ready.set()
+
+    def fail(self, err):
+        if not self.ready.is_set():
+            self.err = err
+            self.ready.set()
+
+
+def join_analysis_level(x_map, level):
+    """Before the coding thread touches the coordinate set / maps of stride 2^level below ``x_map`` (level 1 = the first stride-2 set;
+    level = -1: everything, incl. the hyper-latents' sets): wait for the helper to have put them into the caches, and make the current
+    stream wait for the side stream's kernels behind them.  No-op when nothing was prefetched."""
+    syncs = x_map._cache.get(("analysis_syncs",))
+    if not syncs:
+        return
+    last = level == -1 or level >= len(syncs)
+    sy = syncs[-1] if last else syncs[level - 1]
+    sy.ready.wait()
+    if sy.err is not None:
+        x_map._cache.pop(("analysis_syncs",), None)
+        x_map._cache.pop(("prefetch_job",), None)
+        raise sy.err
+    torch.cuda.current_stream(x_map.device).wait_event(sy.event)
+    if last:
+        x_map._cache.pop(("analysis_syncs",), None)
+        _join_prefetch(x_map)
 
 
 def _join_prefetch(x_map):
@@ -294,14 +352,25 @@ class ConditionEncoder(nn.Module):
         for pid, param in layer.named_parameters():
             self.register_parameter(f"{name}_{pid}".replace(".", "_"), param)
 
-    def forward(self, Q):
+    def begin(self, Q):
+        """pre_conv on the q-map's own set (blocks.py:240)"""
         if self.condition_ablation not in (None, "condition_ablation"):
             raise ValueError(f"condition_ablation={self.condition_ablation!r}: the reference defines None and "
                              "'condition_ablation' only (blocks.py:244-247)")
-        Q = self.pre_conv(Q)
+        return self.pre_conv(Q)
+
+    def stage(self, i, Q):
+        """one level of the pyramid (blocks.py:242-249): -> (the q-map one stride down, that level's beta | gamma).  The analysis
+        transform calls the levels one by one, each in front of its own ScaledBlock — the same values as the reference's loop, which runs
+        all three levels first; the order lets a level's convolutions start while the coarser coordinate sets are still being built."""
+        Q = self.down_layers[i](Q)
+        # configs/Ablation_NoCondition_Convolution.yaml: the down-sampled q-map itself is the (1 + 1)-channel beta | gamma
+        return Q, (self.predict_layers[i](Q) if self.condition_ablation is None else Q)
+
+    def forward(self, Q):
+        Q = self.begin(Q)
         beta_gammas = []
         for i in range(self.num_stages):
-            Q = self.down_layers[i](Q)
-            # configs/Ablation_NoCondition_Convolution.yaml: the down-sampled q-map itself is the (1 + 1)-channel beta | gamma
-            beta_gammas.append(self.predict_layers[i](Q) if self.condition_ablation is None else Q)
+            Q, bg = self.stage(i, Q)
+            beta_gammas.append(bg)
         return Q, beta_gammas

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from . import sparse as sp
-from .blocks import _join_prefetch, prefetch_analysis_maps, prefetch_up_maps, ConditionEncoder, GenerativeUpBlock, ScaledBlock, _conv
+from .blocks import join_analysis_level, prefetch_analysis_maps, prefetch_up_maps, ConditionEncoder, GenerativeUpBlock, ScaledBlock, _conv
 from .sparse import ConvChain, CoordMap, MinkowskiConvolution, MinkowskiReLU, SparseTensor
 
 
@@ -66,22 +66,26 @@ class AnalysisTransform(nn.Module):
             else:
                 Q = SparseTensor(Q.F + Q_plus.features_at_coordinates(Q.C), coordinate_map=Q.map)
         x_in_map = x.map
-        x = self.pre_conv(x)               # (before the condition encoder: the same values in either order — the full-resolution layers
-        #                                    are what the main stream runs while the side stream builds every coarser set and map)
-        if Q.map is x_in_map:
-            prefetch_analysis_maps(x_in_map)
-            _join_prefetch(x_in_map)
-        Q, beta_gammas = self.condition_encoder(Q)
-
-        x = self.down_1(x)
-        x = self.scale_1(x, beta_gammas[0])
-        k.append(self.count_per_batch(x))
-        x = self.down_2(x)
-        x = self.scale_2(x, beta_gammas[1])
-        k.append(self.count_per_batch(x))
-        x = self.down_3(x)
-        x = self.scale_3(x, beta_gammas[2])
+        prefetched = Q.map is x_in_map
+        if prefetched:
+            prefetch_analysis_maps(x_in_map)       # a helper thread builds every coarser set and map on the side stream, level by level
+        x = self.pre_conv(x)
+        ce = self.condition_encoder
+        Q = ce.begin(Q)
+        # level by level: the q-map's pyramid stage, the stride-2 convolution, the ScaledBlock — the reference runs the whole pyramid
+        # first (blocks.py:240-249); the values are the same, and a level's (heavy) convolutions start as soon as ITS maps are there
+        downs, scales = (self.down_1, self.down_2, self.down_3), (self.scale_1, self.scale_2, self.scale_3)
+        for i in range(3):
+            if prefetched:
+                join_analysis_level(x_in_map, i + 1)
+            Q, beta_gamma = ce.stage(i, Q)
+            x = downs[i](x)
+            x = scales[i](x, beta_gamma)
+            if i < 2:
+                k.append(self.count_per_batch(x))
         x = self.post_conv(x)
+        if prefetched:
+            join_analysis_level(x_in_map, -1)      # h_a / h_s's sets and maps (the entropy model looks them up next)
 
         if Q.map is x.map:
             Q8 = Q
