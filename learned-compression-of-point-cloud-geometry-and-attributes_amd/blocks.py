@@ -146,13 +146,22 @@ def prefetch_up_maps(x_map):
     x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
     side.wait_stream(main)
 
+    first = _LevelSync()        # the candidates and the parent -> candidate map: what the up block's first layer needs
+
     def job():
-        with torch.cuda.stream(side):
-            cand = x_map.up(3)
-            x_map.mfma_kernel_map(cand, 3, True)
-            cand.mfma_kernel_map(cand, 3)
-            cand.kernel_map(cand, 3)
-            x_map._cache[("prefetch_event",)] = side.record_event()
+        try:
+            with torch.cuda.stream(side):
+                cand = x_map.up(3)
+                x_map.mfma_kernel_map(cand, 3, True)
+                first.publish(side.record_event())          # the generative convolution can start; the candidates' own map follows
+                cand.mfma_kernel_map(cand, 3)
+                cand.kernel_map(cand, 3)
+                x_map._cache[("prefetch_event",)] = side.record_event()
+        except BaseException as e:
+            first.fail(e)
+            raise
+
+    x_map._cache[("prefetch_first",)] = first
 
     if PREFETCH_THREAD and x_map.n >= PREFETCH_THREAD_MIN_ROWS:
         x_map._cache[("prefetch_job",)] = _helper(dev).submit(job)
@@ -264,7 +273,20 @@ def join_analysis_level(x_map, level):
         _join_prefetch(x_map)
 
 
+def _join_prefetch_first(x_map):
+    """the first publication of prefetch_up_maps (candidates + parent -> candidate map): the rest is joined by _join_prefetch"""
+    sy = x_map._cache.pop(("prefetch_first",), None)
+    if sy is None:
+        return
+    sy.ready.wait()
+    if sy.err is not None:
+        x_map._cache.pop(("prefetch_job",), None)
+        raise sy.err
+    torch.cuda.current_stream(x_map.device).wait_event(sy.event)
+
+
 def _join_prefetch(x_map):
+    x_map._cache.pop(("prefetch_first",), None)
     done = x_map._cache.pop(("prefetch_job",), None)
     if done is not None:
         done.wait()
@@ -293,8 +315,10 @@ class GenerativeUpBlock(nn.Module):
     def forward(self, x, coords=None, k=None, full_predictions=False):
         if not self.predict:
             return self._follow(x, coords)
-        _join_prefetch(x.map)
+        in_map = x.map
+        _join_prefetch_first(in_map)
         x = self.conv(x)                                   # genConvT k3 s2 -> all candidates
+        _join_prefetch(in_map)                             # the candidates' own maps (conv_2, the occupancy head)
         # blocks.py:156-175: dense (the shipped configs) refines the candidates before the occupancy head; dense=False
         # predicts on the raw candidates and refines the kept rows; condition_ablation drops conv_2 in either order
         if self.dense and self.condition_ablation is None:
