@@ -180,7 +180,9 @@ def prefetch_analysis_maps(x_map, levels=5, hyper_ups=2):
     kernel map and execution order of g_a, h_a and h_s are pure functions of the input coordinates.  Built on the side stream
     while the main stream runs the first full-resolution layers (which the caller has already enqueued), instead of one by
     one in front of the layers that use them — ~25 launches and seven count reads per frame, most of them one-workgroup
-    kernels of 30-100 us on sets the chip cannot be filled with.  Inference path only; joined by ``_join_prefetch(x_map)``."""
+    kernels of 30-100 us on sets the chip cannot be filled with.  The calls are made by the helper thread, which publishes every
+    level as soon as its maps are in the caches; the analysis transform takes them up level by level (``join_analysis_level``).
+    Inference path only."""
     if os.environ.get("PCC_PREFETCH_MAPS", "1") == "0" or torch.is_grad_enabled():
         return
     key = ("analysis_prefetched",)
@@ -194,7 +196,6 @@ def prefetch_analysis_maps(x_map, levels=5, hyper_ups=2):
         side = _SIDE_STREAMS[skey] = torch.cuda.Stream(device=dev)
     x_map.table()              # shared with the main stream's own maps of x_map: build it there, before the fork
     side.wait_stream(main)
-    import threading
     # one (host event, stream event) pair per level and one for the rest: the coding thread takes level L's maps up as soon as THEY are
     # there (join_analysis_level) and runs that level's convolutions while the helper goes on with the coarser ones — until round 4's
     # end the main stream stood still for ~2.4 ms at the start of every encode, waiting for all levels behind a single event
